@@ -1,0 +1,125 @@
+/*
+ * knn355.h -- C ABI of libknn355.so, the MI355X (gfx950) kNN hot path.
+ *
+ * The reference (konstin/knn-for-homology) has no FFI layer of its own on this
+ * path: its boundary is the slice of the `faiss` Python module it calls.  Every
+ * entry point below names the faiss call it stands in for and the reference
+ * call sites (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; all matrices row-major, C-contiguous float32
+ *   - "host" functions take host pointers and copy (the caller keeps ownership,
+ *     nothing is retained past return); "_dev" functions take device pointers
+ *     on the index's device and an optional hipStream_t passed as void*
+ *     (NULL = the library's own stream, synchronised before return)
+ *   - return 0 on success, negative on error; knn_last_error() gives the
+ *     thread-local message.  No exceptions or abort() cross the ABI.
+ *   - there is NO CPU fallback: without a usable HIP device every compute
+ *     entry point fails with KNN_ERR_NO_DEVICE.
+ *   - calls on different handles may run concurrently; calls on one handle
+ *     are serialised internally.
+ */
+#ifndef KNN355_H
+#define KNN355_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* faiss.METRIC_INNER_PRODUCT / faiss.METRIC_L2 (cath/search.py:14,31-32;
+ * seqvec_search/main.py:26) */
+#define KNN_METRIC_INNER_PRODUCT 0
+#define KNN_METRIC_L2 1
+
+#define KNN_OK 0
+#define KNN_ERR_INVALID (-1)
+#define KNN_ERR_NO_DEVICE (-2)
+#define KNN_ERR_HIP (-3)
+#define KNN_ERR_UNSUPPORTED (-4)
+#define KNN_ERR_IO (-5)
+
+/* largest k the fused top-k supports (the reference uses k <= 1000:
+ * pfam/proteins_search.py:49) */
+#define KNN_MAX_K 2048
+
+typedef struct knn_index_s *knn_handle;
+
+/* ---- library ---------------------------------------------------------- */
+const char *knn_last_error(void);
+const char *knn_version(void);
+/* number of visible HIP devices (0 if none); never initialises a context */
+int knn_device_count(void);
+/* selects the device used by indexes created afterwards by this thread and
+ * lazily creates its context (fork safe: nothing happens at load time;
+ * cath/compare_seqvec_layer.py:58-64 calls search from forked workers) */
+int knn_init(int device);
+
+/* ---- faiss.normalize_L2(x) --------------------------------------------
+ * in place; rows with zero norm untouched.  cath/search.py:19,
+ * pfam/proteins_search.py:22, seqvec_search/main.py:31,34, pfam/search.py:18,20,
+ * pfam/slices/slices_search.py:18 */
+int knn_normalize_l2(float *x_host, int64_t n, int32_t d);
+int knn_normalize_l2_dev(float *x_dev, int64_t n, int32_t d, void *stream);
+
+/* ---- faiss.IndexFlat(d, metric) ----------------------------------------
+ * cath/search.py:20, pfam/proteins_search.py:24, seqvec_search/main.py:35,
+ * pfam/search.py:44, pfam/slices/slices_search.py:19 */
+int knn_flat_create(int32_t d, int32_t metric, knn_handle *out);
+/* index.add(x): appends n rows (ids = insertion order).  cath/search.py:22,
+ * pfam/proteins_search.py:37, seqvec_search/main.py:39 */
+int knn_flat_add(knn_handle h, const float *x_host, int64_t n);
+int knn_flat_add_dev(knn_handle h, const float *x_dev, int64_t n, void *stream);
+/* index.search(x, k) -> D float32 [nq,k], I int64 [nq,k], best first;
+ * unfilled slots: I=-1, D=-FLT_MAX (IP) / +FLT_MAX (L2).
+ * cath/search.py:24, pfam/proteins_search.py:49, seqvec_search/main.py:45,
+ * pfam/search.py:51, pfam/slices/slices_search.py:28 */
+int knn_flat_search(knn_handle h, const float *q_host, int64_t nq, int64_t k, float *D_host,
+                    int64_t *I_host);
+int knn_flat_search_dev(knn_handle h, const float *q_dev, int64_t nq, int64_t k, float *D_dev,
+                        int64_t *I_dev, void *stream);
+/* per-shard result as packed sortable keys (uint64: order-preserving score
+ * bits << 32 | id_base + local row), k per query, ascending = best first,
+ * padded with UINT64_MAX.  This is what ranks exchange (RCCL all-gather). */
+int knn_flat_search_keys_dev(knn_handle h, const float *q_dev, int64_t nq, int64_t k,
+                             uint32_t id_base, uint64_t *keys_dev, void *stream);
+/* merges nlists key lists per query ([nlists][nq][k], e.g. an all-gather
+ * buffer) into final D/I on the given device */
+int knn_merge_keys_dev(int32_t device, int32_t metric, const uint64_t *keys_dev, int32_t nlists,
+                       int64_t nq, int64_t k, float *D_dev, int64_t *I_dev, void *stream);
+/* index.ntotal / index.d / index.metric_type */
+int64_t knn_ntotal(knn_handle h);
+int32_t knn_dim(knn_handle h);
+int32_t knn_metric(knn_handle h);
+int32_t knn_device_of(knn_handle h);
+/* index.reset() */
+int knn_reset(knn_handle h);
+/* copies rows [i0, i0+n) back to the host (index.reconstruct_n; used by
+ * write_index and by the HNSW builder) */
+int knn_flat_reconstruct(knn_handle h, int64_t i0, int64_t n, float *out_host);
+void knn_free(knn_handle h);
+
+/* ---- distances for explicit candidate lists (HNSW walk offload) --------
+ * For query i (row of q_dev [nq,d]) and candidates cand[off[i] .. off[i+1]),
+ * out[p] = <q,y> (IP) or max(0, |q|^2+|y|^2-2<q,y>) (L2), same arithmetic as
+ * the flat scan.  Replaces the per-candidate distance computer inside
+ * faiss.IndexHNSWFlat (pfam/proteins_search.py:30-31,49). */
+int knn_gather_distances(knn_handle h, const float *q_host, int64_t nq, const int64_t *cand_ids,
+                         const int64_t *cand_offsets, float *out_host);
+
+/* ---- tuning / introspection (not part of the faiss surface) ------------ */
+/* name of the scan kernel the last search on this handle dispatched, and its
+ * geometry; used by bench.py for the roofline line */
+int knn_last_scan_info(knn_handle h, char *name, int32_t name_len, int32_t *query_tile,
+                       int32_t *db_tile, int32_t *nchunks, int32_t *grid);
+/* device time (ms) of the scan kernel launches of the last search, measured
+ * with hipEvents on the launch stream */
+float knn_last_scan_ms(knn_handle h);
+/* force a scan configuration: query_tile in {0(auto),32,64,128}; nchunks 0=auto */
+int knn_set_tuning(knn_handle h, int32_t query_tile, int32_t nchunks, int32_t flags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KNN355_H */

@@ -1,0 +1,86 @@
+"""ctypes binding of libknn355.so (C ABI: include/knn355.h).
+
+Nothing touches HIP at import time: the shared object is dlopen'ed on first use and
+the library itself creates its HIP context lazily, so forked workers
+(cath/compare_seqvec_layer.py:58-64 in the reference) are safe.
+
+If ``torch`` is going to be used in the same process (multi-GPU path, bench.py),
+import it BEFORE the first call here so that both share one HIP runtime
+(torch ships its own libamdhip64 with the same SONAME).
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_uint32, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libknn355.so")
+
+_lib = None
+
+
+class Knn355Error(RuntimeError):
+    """Raised for every non-zero return code of the C ABI (FAISS surfaces its C++
+    exceptions as RuntimeError too)."""
+
+
+def _declare(L):
+    f32p, i64p, u64p = POINTER(c_float), POINTER(c_int64), POINTER(c_uint64)
+    H = c_void_p
+    sig = {
+        "knn_last_error": (c_char_p, []),
+        "knn_version": (c_char_p, []),
+        "knn_device_count": (c_int32, []),
+        "knn_init": (c_int32, [c_int32]),
+        "knn_normalize_l2": (c_int32, [c_void_p, c_int64, c_int32]),
+        "knn_normalize_l2_dev": (c_int32, [c_void_p, c_int64, c_int32, c_void_p]),
+        "knn_flat_create": (c_int32, [c_int32, c_int32, POINTER(H)]),
+        "knn_flat_add": (c_int32, [H, c_void_p, c_int64]),
+        "knn_flat_add_dev": (c_int32, [H, c_void_p, c_int64, c_void_p]),
+        "knn_flat_search": (c_int32, [H, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+        "knn_flat_search_dev": (c_int32, [H, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+        "knn_flat_search_keys_dev": (c_int32, [H, c_void_p, c_int64, c_int64, c_uint32, c_void_p, c_void_p]),
+        "knn_merge_keys_dev": (c_int32, [c_int32, c_int32, c_void_p, c_int32, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+        "knn_ntotal": (c_int64, [H]),
+        "knn_dim": (c_int32, [H]),
+        "knn_metric": (c_int32, [H]),
+        "knn_device_of": (c_int32, [H]),
+        "knn_reset": (c_int32, [H]),
+        "knn_flat_reconstruct": (c_int32, [H, c_int64, c_int64, c_void_p]),
+        "knn_free": (None, [H]),
+        "knn_gather_distances": (c_int32, [H, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+        "knn_last_scan_info": (c_int32, [H, c_char_p, c_int32, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
+        "knn_last_scan_ms": (c_float, [H]),
+        "knn_set_tuning": (c_int32, [H, c_int32, c_int32, c_int32]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError here == the library does not export the ABI
+        fn.restype = res
+        fn.argtypes = args
+    return sig
+
+
+EXPORTS = None
+
+
+def lib():
+    """Returns the loaded library; raises Knn355Error if it has not been built."""
+    global _lib, EXPORTS
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Knn355Error(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C knn-for-homology_amd/csrc` (there is no CPU fallback)")
+        L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL if hasattr(ctypes, "RTLD_GLOBAL") else 0)
+        EXPORTS = _declare(L)
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().knn_last_error()
+        raise Knn355Error((msg or b"unknown error").decode("utf-8", "replace") + f" (code {rc})")
+
+
+def device_count():
+    return int(lib().knn_device_count())

@@ -1,0 +1,57 @@
+"""Drop-in for the reference's ``cath/search.py`` (all-vs-all CATH20 search).
+
+``search`` keeps the reference contract (cath/search.py:13-26):
+  * one extra neighbour is requested and column 0 (the self hit) is dropped,
+  * the return order is ``(hits int64 [N,hits], scores float32 [N,hits])`` -- ids first,
+    i.e. swapped relative to ``index.search``,
+  * for the inner-product metric the rows are L2-normalised on a COPY (the caller's
+    array is left alone); for L2 nothing is normalised.
+``search_and_save`` keeps the file protocol (cath/search.py:29-53): for "Cosine" and
+"Euclidean", every ``*.npy`` in the data directory (fp16 files are cast to fp32) is
+searched, ``<stem>.<metric>-search-time.txt`` records the wall time of
+copy+normalise+add+search, and ``hits_<metric>.npz`` / ``scores_<metric>.npz`` hold one
+array per file stem.
+"""
+import time
+from pathlib import Path
+from typing import Optional, Tuple
+
+import numpy
+from numpy import ndarray
+
+from .. import faiss
+from ..paths import cath_data as _default_cath_data
+
+_METRICS = (("Cosine", faiss.METRIC_INNER_PRODUCT), ("Euclidean", faiss.METRIC_L2))
+
+
+def search(embeddings: ndarray, hits: int = 10, metric=faiss.METRIC_INNER_PRODUCT) -> Tuple[ndarray, ndarray]:
+    vectors = embeddings
+    if metric == faiss.METRIC_INNER_PRODUCT:
+        vectors = numpy.array(embeddings, dtype=numpy.float32, order="C", copy=True)
+        faiss.normalize_L2(vectors)
+    index = faiss.IndexFlat(vectors.shape[1], metric)
+    index.add(vectors)
+    scores, neighbours = index.search(vectors, hits + 1)
+    return neighbours[:, 1:], scores[:, 1:]
+
+
+def search_and_save(cath_data: Optional[Path] = None):
+    data_dir = Path(cath_data) if cath_data is not None else _default_cath_data()
+    for label, metric in _METRICS:
+        print(f"Searching with {label}")
+        all_hits, all_scores = {}, {}
+        for npy in sorted(data_dir.glob("*.npy")):
+            embeddings = numpy.load(npy).astype(numpy.float32)
+            print(npy.stem, embeddings.shape)
+            t0 = time.time()
+            all_hits[npy.stem], all_scores[npy.stem] = search(embeddings, metric=metric)
+            elapsed = time.time() - t0
+            print(elapsed)
+            npy.with_suffix(f".{label.lower()}-search-time.txt").write_text(str(elapsed))
+        numpy.savez(data_dir / f"hits_{label.lower()}.npz", **all_hits)
+        numpy.savez(data_dir / f"scores_{label.lower()}.npz", **all_scores)
+
+
+if __name__ == "__main__":
+    search_and_save()

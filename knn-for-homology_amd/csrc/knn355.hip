@@ -1,0 +1,1177 @@
+// knn355.hip -- MI355X (gfx950 / CDNA4) flat kNN: distance + fused top-k.
+//
+// Stands in for faiss-cpu 1.7.2's IndexFlat / normalize_L2 as called by the
+// reference (cath/search.py:13-26, seqvec_search/main.py:22-50,
+// pfam/proteins_search.py:21-50, pfam/search.py:42-53,
+// pfam/slices/slices_search.py:15-31).  C ABI: include/knn355.h.
+//
+// Arithmetic contract (bit-exact with oracle/knn_oracle.c):
+//   dot(x,y)  one fp32 fma chain per (query,row) pair, k visited per 8-block in
+//             the order 0,4,1,5,2,6,3,7 -- exactly what v_mfma_f32_32x32x2_f32
+//             produces when lane (i,h) feeds floats 8t+4h+m for m = 0..3
+//   nrm(x)    64 lane-partial fma chains + xor butterfly
+//   L2        max(0, fma(-2, dot, nrm(x)+nrm(y)))
+//   ties      lower row id first (packed 64-bit keys: score bits << 32 | row)
+//
+// Kernel plan (DESIGN.md has the long form):
+//   flat_scan_kernel   one workgroup = QT queries x one chunk of database rows.
+//                      Per 32-float K step both operands are staged into LDS
+//                      with global_load_lds_dwordx4 (full 128-B lines,
+//                      XOR-swizzled on the source address), fragments come
+//                      back with ds_read_b128, fp32 MFMA accumulates the
+//                      QT x DT score tile; the epilogue compares every score
+//                      with a running per-query threshold and appends the
+//                      survivors as packed keys; lists are compacted in LDS.
+//   merge_keys_kernel  k-way merge of per-chunk / per-shard key lists.
+//   finalize_kernel    keys -> (float D, int64 I).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <float.h>
+#include <math.h>
+#include <algorithm>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/knn355.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define KEY_PAD 0xFFFFFFFFFFFFFFFFull
+
+// ---------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t f2ord(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o)
+{
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __uint_as_float(u);
+}
+
+__device__ __forceinline__ float wave_norm_row(const float *__restrict__ row, int d, int lane)
+{
+    float acc = 0.0f;
+    for (int e0 = 0; e0 < d; e0 += 256) {
+        int e = e0 + 4 * lane;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        if (e + 3 < d) {
+            f32x4 v = *(const f32x4 *)(row + e);
+            v0 = v[0]; v1 = v[1]; v2 = v[2]; v3 = v[3];
+        } else {
+            if (e < d) v0 = row[e];
+            if (e + 1 < d) v1 = row[e + 1];
+            if (e + 2 < d) v2 = row[e + 2];
+        }
+        acc = __builtin_fmaf(v0, v0, acc);
+        acc = __builtin_fmaf(v1, v1, acc);
+        acc = __builtin_fmaf(v2, v2, acc);
+        acc = __builtin_fmaf(v3, v3, acc);
+    }
+    for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off, 64);
+    return acc;
+}
+
+// rows must be 16-byte aligned when d % 4 == 0 (stride multiple of 4 floats)
+__global__ void norm_rows_kernel(const float *__restrict__ x, int64_t n, int d, int64_t stride,
+                                 float *__restrict__ out)
+{
+    int lane = threadIdx.x & 63;
+    int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    float nr = wave_norm_row(x + row * stride, d, lane);
+    if (lane == 0) out[row] = nr;
+}
+
+__global__ void normalize_rows_kernel(float *__restrict__ x, int64_t n, int d, int64_t stride)
+{
+    int lane = threadIdx.x & 63;
+    int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    float *r = x + row * stride;
+    float nr = wave_norm_row(r, d, lane);
+    if (nr > 0.0f) {
+        const float inv = (float)(1.0 / (double)__fsqrt_rn(nr));
+        for (int e0 = 0; e0 < d; e0 += 256) {
+            int e = e0 + 4 * lane;
+            if (e + 3 < d) {
+                f32x4 v = *(f32x4 *)(r + e);
+                v[0] *= inv; v[1] *= inv; v[2] *= inv; v[3] *= inv;
+                *(f32x4 *)(r + e) = v;
+            } else {
+                for (int c = 0; c < 3; c++)
+                    if (e + c < d) r[e + c] *= inv;
+            }
+        }
+    }
+}
+
+// scalar-path variants for rows that are not 16-byte aligned (d % 4 != 0)
+__global__ void norm_rows_unaligned_kernel(const float *__restrict__ x, int64_t n, int d,
+                                           int64_t stride, float *__restrict__ out, int normalize,
+                                           float *__restrict__ xw)
+{
+    int lane = threadIdx.x & 63;
+    int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float *r = x + row * stride;
+    float acc = 0.0f;
+    for (int e0 = 0; e0 < d; e0 += 256) {
+        for (int c = 0; c < 4; c++) {
+            int e = e0 + 4 * lane + c;
+            float v = e < d ? r[e] : 0.0f;
+            acc = __builtin_fmaf(v, v, acc);
+        }
+    }
+    for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off, 64);
+    if (out && lane == 0) out[row] = acc;
+    if (normalize && acc > 0.0f) {
+        const float inv = (float)(1.0 / (double)__fsqrt_rn(acc));
+        float *w = xw + row * stride;
+        for (int e = lane; e < d; e += 64) w[e] *= inv;
+    }
+}
+
+// dst[n][dp] <- src[n][d], zero padded
+__global__ void pad_rows_kernel(const float *__restrict__ src, int64_t n, int d,
+                                float *__restrict__ dst, int dp)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = n * dp;
+    for (; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i / dp;
+        int c = (int)(i - r * dp);
+        dst[i] = c < d ? src[r * d + c] : 0.0f;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// workgroup-wide bitonic sort of P (power of two) u64 keys in LDS, ascending
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void wg_bitonic_sort(uint64_t *sb, int P, int tid, int nthreads)
+{
+    for (int k2 = 2; k2 <= P; k2 <<= 1) {
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < (P >> 1); i += nthreads) {
+                int a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                int b = a + j;
+                bool up = (a & k2) == 0;
+                uint64_t x = sb[a], y = sb[b];
+                if ((x > y) == up) { sb[a] = y; sb[b] = x; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ __forceinline__ int next_pow2_dev(int n)
+{
+    int p = 64;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+// ---------------------------------------------------------------------------
+// scan kernel
+// ---------------------------------------------------------------------------
+struct ScanParams {
+    const float *xb;   // [nb][dp] database rows, zero padded to dp
+    const float *yn;   // [nb] squared norms (L2 only)
+    const float *xq;   // [nq][dp] queries
+    const float *xn;   // [nq] squared norms (L2 only)
+    int64_t nb, nq;
+    int dp;            // multiple of 32
+    int k;
+    int cap;           // candidate list capacity per (workgroup, query); power of two
+    int nqtiles, nchunks;
+    int64_t chunk_rows; // multiple of the database tile
+    uint64_t *lists;   // [grid][QT][cap]
+    uint32_t *gthr;    // [nqtiles*QT] shared running thresholds (order-mapped floats)
+    uint64_t *partial; // [nq][nchunks][k]
+    uint32_t id_base;
+};
+
+template <bool GLDS>
+__device__ __forceinline__ void stage_issue(const float *src, char *lds_wave_base, int lane, f32x4 &reg)
+{
+    if constexpr (GLDS) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+    } else {
+        reg = *(const f32x4 *)src;
+    }
+}
+
+// WM x WN waves; each wave owns TM x TN MFMA tiles of 32(db rows) x 32(queries)
+template <int WM, int WN, int TM, int TN, bool L2, bool GLDS>
+__global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
+{
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int DT = WM * TM * 32;        // database rows per tile
+    constexpr int QT = WN * TN * 32;        // queries per workgroup
+    constexpr int ROWS = DT + QT;           // staged rows per K step
+    constexpr int NI = ROWS / 8 / 4;        // staging instructions per wave per K step
+    static_assert(ROWS % 32 == 0, "staging split");
+    constexpr int STAGE_BYTES = ROWS * 128; // 32 floats per row
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *stage0 = smem;
+    char *stage1 = smem + STAGE_BYTES;
+    float *s_thr = (float *)(smem + 2 * STAGE_BYTES);
+    int *s_cnt = (int *)(s_thr + QT);
+    int *s_need = s_cnt + QT;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int qtile = blockIdx.x % p.nqtiles;
+    const int chunk = blockIdx.x / p.nqtiles;
+    const int64_t q0 = (int64_t)qtile * QT;
+    const int64_t c_lo = (int64_t)chunk * p.chunk_rows;
+    const int64_t c_hi = min(p.nb, c_lo + p.chunk_rows);
+    uint64_t *my_lists = p.lists + (size_t)blockIdx.x * QT * p.cap;
+    const int KT = p.dp / 32;
+
+    for (int i = tid; i < QT; i += 256) {
+        s_thr[i] = INFINITY;
+        s_cnt[i] = 0;
+    }
+    if (tid == 0) *s_need = 0;
+    __syncthreads();
+
+    // per-lane staging bookkeeping: instruction ii covers combined rows 8*ii..8*ii+7
+    const float *srcp[NI];
+    int lds_off[NI];
+    bool is_db[NI];
+    int rloc[NI];
+#pragma unroll
+    for (int n = 0; n < NI; n++) {
+        int ii = wave + 4 * n;
+        int row_local = 8 * ii + (lane >> 3);
+        int sp = lane & 7;
+        lds_off[n] = ii * 1024;
+        if (row_local < DT) {
+            is_db[n] = true;
+            rloc[n] = row_local;
+            int s = sp ^ ((row_local >> 1) & 7);
+            srcp[n] = p.xb + 4 * s; // row added per tile
+        } else {
+            is_db[n] = false;
+            int rq = row_local - DT;
+            rloc[n] = rq;
+            int s = sp ^ ((rq >> 1) & 7);
+            int64_t q = min(q0 + rq, p.nq - 1);
+            srcp[n] = p.xq + q * p.dp + 4 * s;
+        }
+    }
+    const int swz = (li >> 1) & 7;
+
+    for (int64_t row0 = c_lo; row0 < c_hi; row0 += DT) {
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int a = 0; a < TM; a++)
+#pragma unroll
+            for (int b = 0; b < TN; b++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
+
+        const float *tsrc[NI];
+#pragma unroll
+        for (int n = 0; n < NI; n++) {
+            if (is_db[n]) {
+                int64_t r = min(row0 + rloc[n], p.nb - 1);
+                tsrc[n] = srcp[n] + r * p.dp;
+            } else {
+                tsrc[n] = srcp[n];
+            }
+        }
+        f32x4 sreg[NI];
+        // prologue: stage K step 0 into buffer 0
+#pragma unroll
+        for (int n = 0; n < NI; n++) {
+            stage_issue<GLDS>(tsrc[n], stage0 + lds_off[n], lane, sreg[n]);
+            if constexpr (!GLDS) *(f32x4 *)(stage0 + lds_off[n] + lane * 16) = sreg[n];
+        }
+
+        for (int kt = 0; kt < KT; kt++) {
+            char *cur = (kt & 1) ? stage1 : stage0;
+            char *nxt = (kt & 1) ? stage0 : stage1;
+            __syncthreads(); // stage kt landed (vmcnt(0) + barrier); buffer nxt is free
+            if (kt + 1 < KT) {
+#pragma unroll
+                for (int n = 0; n < NI; n++)
+                    stage_issue<GLDS>(tsrc[n] + (kt + 1) * 32, nxt + lds_off[n], lane, sreg[n]);
+            }
+            const char *A = cur;
+            const char *B = cur + DT * 128;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                f32x4 af[TM], bf[TN];
+                const int slot = ((2 * t + lh) ^ swz) * 16;
+#pragma unroll
+                for (int a = 0; a < TM; a++)
+                    af[a] = *(const f32x4 *)(A + ((wm * TM + a) * 32 + li) * 128 + slot);
+#pragma unroll
+                for (int b = 0; b < TN; b++)
+                    bf[b] = *(const f32x4 *)(B + ((wn * TN + b) * 32 + li) * 128 + slot);
+#pragma unroll
+                for (int m = 0; m < 4; m++)
+#pragma unroll
+                    for (int a = 0; a < TM; a++)
+#pragma unroll
+                        for (int b = 0; b < TN; b++)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][m], bf[b][m], acc[a][b], 0, 0, 0);
+            }
+            if constexpr (!GLDS) {
+                if (kt + 1 < KT) {
+#pragma unroll
+                    for (int n = 0; n < NI; n++) *(f32x4 *)(nxt + lds_off[n] + lane * 16) = sreg[n];
+                }
+            }
+        }
+
+        // ---- epilogue: threshold filter + append ----
+#pragma unroll
+        for (int b = 0; b < TN; b++) {
+            const int ql = (wn * TN + b) * 32 + li;
+            const int64_t q = q0 + ql;
+            const bool qok = q < p.nq;
+            float thr = s_thr[ql];
+            {
+                uint32_t g = __hip_atomic_load(&p.gthr[qtile * QT + ql], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                thr = fminf(thr, ord2f(g));
+            }
+            float xnq = 0.0f;
+            if constexpr (L2) xnq = p.xn[qok ? q : 0];
+#pragma unroll
+            for (int a = 0; a < TM; a++) {
+                const int64_t rbase = row0 + (wm * TM + a) * 32 + 4 * lh;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
+                    float v;
+                    if constexpr (L2) {
+                        float ynr = p.yn[min(row, p.nb - 1)];
+                        float t = xnq + ynr;
+                        v = __builtin_fmaf(-2.0f, acc[a][b][r], t);
+                        v = v < 0.0f ? 0.0f : v;
+                    } else {
+                        v = -acc[a][b][r];
+                    }
+                    if (v <= thr && row < c_hi && qok) {
+                        v = v + 0.0f;
+                        int slot = atomicAdd(&s_cnt[ql], 1);
+                        if (slot < p.cap)
+                            my_lists[(size_t)ql * p.cap + slot] =
+                                ((uint64_t)f2ord(v) << 32) | (uint32_t)(p.id_base + (uint32_t)row);
+                        if (slot + 1 > p.cap - DT) *s_need = 1;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- compaction of lists that could overflow on the next tile ----
+        const bool last_tile = row0 + DT >= c_hi;
+        if (*s_need || last_tile) {
+            uint64_t *sb = (uint64_t *)smem;
+            for (int ql = 0; ql < QT; ql++) {
+                const int n = min(s_cnt[ql], p.cap);
+                if (!last_tile && n <= p.cap - DT) continue;
+                const int64_t q = q0 + ql;
+                uint64_t *lst = my_lists + (size_t)ql * p.cap;
+                const int P = next_pow2_dev(n > 0 ? n : 1);
+                for (int i = tid; i < P; i += 256) sb[i] = i < n ? lst[i] : KEY_PAD;
+                __syncthreads();
+                wg_bitonic_sort(sb, P, tid, 256);
+                const int keep = min(n, p.k);
+                if (!last_tile) {
+                    for (int i = tid; i < keep; i += 256) lst[i] = sb[i];
+                } else if (q < p.nq) {
+                    uint64_t *out = p.partial + ((size_t)q * p.nchunks + chunk) * p.k;
+                    for (int i = tid; i < p.k; i += 256) out[i] = i < keep ? sb[i] : KEY_PAD;
+                }
+                if (tid == 0) {
+                    s_cnt[ql] = keep;
+                    if (n >= p.k) {
+                        uint32_t o = (uint32_t)(sb[p.k - 1] >> 32);
+                        s_thr[ql] = ord2f(o);
+                        atomicMin(&p.gthr[qtile * QT + ql], o);
+                    }
+                }
+                __syncthreads();
+            }
+            if (tid == 0) *s_need = 0;
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// merge: in [nq][L][k] (or [L][nq][k] when list_major) -> out [nq][Lout][k]
+// each workgroup sorts the union of up to G lists of one query
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void merge_keys_kernel(const uint64_t *__restrict__ in, int L, int k,
+                                                         int64_t nq, int list_major, int G, int Lout,
+                                                         uint64_t *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t *sb = (uint64_t *)smem;
+    const int tid = threadIdx.x;
+    const int64_t q = blockIdx.x / Lout;
+    const int g = blockIdx.x % Lout;
+    const int l0 = g * G, l1 = min(L, l0 + G);
+    const int n = (l1 - l0) * k;
+    int P = 64;
+    while (P < n) P <<= 1;
+    for (int i = tid; i < P; i += 256) {
+        uint64_t v = KEY_PAD;
+        if (i < n) {
+            int l = l0 + i / k, j = i % k;
+            size_t idx = list_major ? ((size_t)l * nq + q) * k + j : ((size_t)q * L + l) * k + j;
+            v = in[idx];
+        }
+        sb[i] = v;
+    }
+    __syncthreads();
+    wg_bitonic_sort(sb, P, tid, 256);
+    uint64_t *o = out + ((size_t)q * Lout + g) * k;
+    for (int i = tid; i < k; i += 256) o[i] = i < n ? sb[i] : KEY_PAD;
+}
+
+__global__ void finalize_kernel(const uint64_t *__restrict__ keys, int64_t total, int metric,
+                                float *__restrict__ D, int64_t *__restrict__ I)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    uint64_t key = keys[i];
+    if (key == KEY_PAD) {
+        D[i] = metric == KNN_METRIC_INNER_PRODUCT ? -FLT_MAX : FLT_MAX;
+        I[i] = -1;
+    } else {
+        float v = ord2f((uint32_t)(key >> 32));
+        D[i] = metric == KNN_METRIC_INNER_PRODUCT ? -v : v;
+        I[i] = (int64_t)(uint32_t)key;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// gather distances: one wave per (query, candidate) pair, same fma chain order
+// ---------------------------------------------------------------------------
+__global__ void pair_distance_kernel(const float *__restrict__ xb, const float *__restrict__ yn,
+                                     const float *__restrict__ xq, const float *__restrict__ xn,
+                                     int dp, int metric, int64_t npairs,
+                                     const int32_t *__restrict__ pair_q, const int64_t *__restrict__ pair_r,
+                                     float *__restrict__ out)
+{
+    // Each lane runs whole chains for separate pairs (the chain is sequential in k).
+    int64_t pidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pidx >= npairs) return;
+    const float *q = xq + (int64_t)pair_q[pidx] * dp;
+    const float *y = xb + pair_r[pidx] * dp;
+    float acc = 0.0f;
+    for (int k0 = 0; k0 < dp; k0 += 8) {
+        f32x4 q0 = *(const f32x4 *)(q + k0), q1 = *(const f32x4 *)(q + k0 + 4);
+        f32x4 y0 = *(const f32x4 *)(y + k0), y1 = *(const f32x4 *)(y + k0 + 4);
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            acc = __builtin_fmaf(q0[m], y0[m], acc);
+            acc = __builtin_fmaf(q1[m], y1[m], acc);
+        }
+    }
+    if (metric == KNN_METRIC_L2) {
+        float t = xn[pair_q[pidx]] + yn[pair_r[pidx]];
+        float v = __builtin_fmaf(-2.0f, acc, t);
+        acc = v < 0.0f ? 0.0f : v;
+    }
+    out[pidx] = acc;
+}
+
+// ===========================================================================
+// host side
+// ===========================================================================
+static thread_local std::string g_err;
+static thread_local int g_device = 0;
+
+static int set_err(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return set_err(KNN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need)
+    {
+        if (need <= bytes) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        size_t want = need + need / 4;
+        if (hipMalloc(&p, want) != hipSuccess) {
+            if (hipMalloc(&p, need) != hipSuccess) return -1;
+            want = need;
+        }
+        bytes = want;
+        return 0;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+struct knn_index_s {
+    int d = 0, dp = 0, metric = 0, device = 0;
+    int64_t ntotal = 0, cap_rows = 0;
+    float *xb = nullptr; // [cap_rows][dp]
+    float *yn = nullptr; // [cap_rows + pad]
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::mutex mu;
+    DevBuf ws_q, ws_qn, ws_lists, ws_gthr, ws_partial, ws_partial2, ws_keys, ws_D, ws_I, ws_tmp, ws_tmp2;
+    // tuning + introspection
+    int force_qt = 0, force_chunks = 0, flags = 0;
+    std::string last_kernel;
+    int last_qt = 0, last_dt = 0, last_chunks = 0, last_grid = 0;
+    float last_ms = 0.f;
+};
+
+static int ensure_device(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return set_err(KNN_ERR_NO_DEVICE, "no HIP device available (libknn355 has no CPU fallback)");
+    if (device < 0 || device >= n) return set_err(KNN_ERR_INVALID, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    return 0;
+}
+
+extern "C" const char *knn_last_error(void) { return g_err.c_str(); }
+extern "C" const char *knn_version(void) { return "knn355 0.1 (gfx950)"; }
+extern "C" int knn_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+extern "C" int knn_init(int device)
+{
+    int rc = ensure_device(device);
+    if (rc) return rc;
+    g_device = device;
+    return 0;
+}
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// ---- normalize ------------------------------------------------------------
+static int normalize_dev_impl(float *x, int64_t n, int d, int64_t stride, hipStream_t s)
+{
+    if (n == 0) return 0;
+    const int wpb = 4;
+    unsigned grid = (unsigned)((n + wpb - 1) / wpb);
+    if ((stride % 4) == 0 && (((uintptr_t)x) % 16) == 0)
+        hipLaunchKernelGGL(normalize_rows_kernel, dim3(grid), dim3(64 * wpb), 0, s, x, n, d, stride);
+    else
+        hipLaunchKernelGGL(norm_rows_unaligned_kernel, dim3(grid), dim3(64 * wpb), 0, s, x, n, d, stride,
+                           (float *)nullptr, 1, x);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+static int norms_dev_impl(const float *x, int64_t n, int d, int64_t stride, float *out, hipStream_t s)
+{
+    if (n == 0) return 0;
+    const int wpb = 4;
+    unsigned grid = (unsigned)((n + wpb - 1) / wpb);
+    if ((stride % 4) == 0 && (((uintptr_t)x) % 16) == 0)
+        hipLaunchKernelGGL(norm_rows_kernel, dim3(grid), dim3(64 * wpb), 0, s, x, n, d, stride, out);
+    else
+        hipLaunchKernelGGL(norm_rows_unaligned_kernel, dim3(grid), dim3(64 * wpb), 0, s, x, n, d, stride, out,
+                           0, (float *)nullptr);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int knn_normalize_l2_dev(float *x_dev, int64_t n, int32_t d, void *stream)
+{
+    if (n < 0 || d <= 0) return set_err(KNN_ERR_INVALID, "normalize_l2: bad shape");
+    int rc = normalize_dev_impl(x_dev, n, d, d, (hipStream_t)stream);
+    if (rc) return rc;
+    if (!stream) HIP_TRY(hipStreamSynchronize(nullptr));
+    return 0;
+}
+
+extern "C" int knn_normalize_l2(float *x_host, int64_t n, int32_t d)
+{
+    if (n < 0 || d <= 0) return set_err(KNN_ERR_INVALID, "normalize_l2: bad shape");
+    if (n == 0) return 0;
+    if (!x_host) return set_err(KNN_ERR_INVALID, "normalize_l2: null pointer");
+    int rc = ensure_device(g_device);
+    if (rc) return rc;
+    // stream through a bounded device buffer (<= 1 GiB)
+    const int64_t rows_per = std::max<int64_t>(1, (int64_t)(1ull << 30) / ((int64_t)d * 4));
+    const int64_t nb = std::min(n, rows_per);
+    float *buf = nullptr;
+    HIP_TRY(hipMalloc((void **)&buf, (size_t)nb * d * 4));
+    for (int64_t i0 = 0; i0 < n; i0 += nb) {
+        int64_t m = std::min(nb, n - i0);
+        hipError_t e = hipMemcpy(buf, x_host + i0 * d, (size_t)m * d * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            rc = normalize_dev_impl(buf, m, d, d, nullptr);
+            if (rc) { (void)hipFree(buf); return rc; }
+            e = hipMemcpy(x_host + i0 * d, buf, (size_t)m * d * 4, hipMemcpyDeviceToHost);
+        }
+        if (e != hipSuccess) {
+            (void)hipFree(buf);
+            return set_err(KNN_ERR_HIP, std::string("normalize_l2 copy: ") + hipGetErrorString(e));
+        }
+    }
+    HIP_TRY(hipFree(buf));
+    return 0;
+}
+
+// ---- index lifecycle ------------------------------------------------------
+extern "C" int knn_flat_create(int32_t d, int32_t metric, knn_handle *out)
+{
+    if (!out) return set_err(KNN_ERR_INVALID, "flat_create: null out");
+    if (d <= 0) return set_err(KNN_ERR_INVALID, "flat_create: d must be positive");
+    if (metric != KNN_METRIC_INNER_PRODUCT && metric != KNN_METRIC_L2)
+        return set_err(KNN_ERR_UNSUPPORTED, "flat_create: metric must be METRIC_INNER_PRODUCT (0) or METRIC_L2 (1)");
+    int rc = ensure_device(g_device);
+    if (rc) return rc;
+    knn_index_s *h = new knn_index_s();
+    h->d = d;
+    h->dp = round_up(d, 32);
+    h->metric = metric;
+    h->device = g_device;
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+        delete h;
+        return set_err(KNN_ERR_HIP, "flat_create: stream/event creation failed");
+    }
+    *out = h;
+    return 0;
+}
+
+static void free_index_buffers(knn_index_s *h)
+{
+    if (h->xb) (void)hipFree(h->xb);
+    if (h->yn) (void)hipFree(h->yn);
+    h->xb = nullptr;
+    h->yn = nullptr;
+    h->ntotal = 0;
+    h->cap_rows = 0;
+}
+
+extern "C" void knn_free(knn_handle h)
+{
+    if (!h) return;
+    if (hipSetDevice(h->device) == hipSuccess) {
+        free_index_buffers(h);
+        DevBuf *bufs[] = {&h->ws_q, &h->ws_qn, &h->ws_lists, &h->ws_gthr, &h->ws_partial, &h->ws_partial2,
+                          &h->ws_keys, &h->ws_D, &h->ws_I, &h->ws_tmp, &h->ws_tmp2};
+        for (DevBuf *b : bufs) b->release();
+        if (h->ev0) (void)hipEventDestroy(h->ev0);
+        if (h->ev1) (void)hipEventDestroy(h->ev1);
+        if (h->stream) (void)hipStreamDestroy(h->stream);
+    }
+    delete h;
+}
+
+extern "C" int64_t knn_ntotal(knn_handle h) { return h ? h->ntotal : -1; }
+extern "C" int32_t knn_dim(knn_handle h) { return h ? h->d : -1; }
+extern "C" int32_t knn_metric(knn_handle h) { return h ? h->metric : -1; }
+extern "C" int32_t knn_device_of(knn_handle h) { return h ? h->device : -1; }
+
+extern "C" int knn_reset(knn_handle h)
+{
+    if (!h) return set_err(KNN_ERR_INVALID, "reset: null handle");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->device));
+    free_index_buffers(h);
+    return 0;
+}
+
+static int grow_index(knn_index_s *h, int64_t need_rows)
+{
+    if (need_rows <= h->cap_rows) return 0;
+    int64_t new_cap = std::max<int64_t>(need_rows, h->cap_rows + h->cap_rows / 2);
+    if (h->cap_rows == 0) new_cap = need_rows; // first add: exact fit (the reference adds once)
+    float *nxb = nullptr, *nyn = nullptr;
+    size_t row_bytes = (size_t)h->dp * 4;
+    if (hipMalloc((void **)&nxb, (size_t)new_cap * row_bytes) != hipSuccess) {
+        new_cap = need_rows;
+        HIP_TRY(hipMalloc((void **)&nxb, (size_t)new_cap * row_bytes));
+    }
+    if (hipMalloc((void **)&nyn, ((size_t)new_cap + 64) * 4) != hipSuccess) {
+        (void)hipFree(nxb);
+        return set_err(KNN_ERR_HIP, "add: out of device memory");
+    }
+    if (h->ntotal > 0) {
+        HIP_TRY(hipMemcpyAsync(nxb, h->xb, (size_t)h->ntotal * row_bytes, hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(nyn, h->yn, (size_t)h->ntotal * 4, hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    if (h->xb) (void)hipFree(h->xb);
+    if (h->yn) (void)hipFree(h->yn);
+    h->xb = nxb;
+    h->yn = nyn;
+    h->cap_rows = new_cap;
+    return 0;
+}
+
+// appends rows that already live on the device ([n][d], contiguous)
+static int add_dev_impl(knn_index_s *h, const float *x_dev, int64_t n, hipStream_t s)
+{
+    float *dst = h->xb + (size_t)h->ntotal * h->dp;
+    if (h->dp == h->d) {
+        HIP_TRY(hipMemcpyAsync(dst, x_dev, (size_t)n * h->d * 4, hipMemcpyDeviceToDevice, s));
+    } else {
+        int64_t total = n * h->dp;
+        unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 65535);
+        hipLaunchKernelGGL(pad_rows_kernel, dim3(grid), dim3(256), 0, s, x_dev, n, h->d, dst, h->dp);
+        HIP_TRY(hipGetLastError());
+    }
+    // norms are kept for both metrics: reconstruct/HNSW-L2 need them and they cost one pass
+    int rc = norms_dev_impl(dst, n, h->d, h->dp, h->yn + h->ntotal, s);
+    if (rc) return rc;
+    h->ntotal += n;
+    return 0;
+}
+
+extern "C" int knn_flat_add_dev(knn_handle h, const float *x_dev, int64_t n, void *stream)
+{
+    if (!h) return set_err(KNN_ERR_INVALID, "add: null handle");
+    if (n < 0) return set_err(KNN_ERR_INVALID, "add: negative n");
+    if (n == 0) return 0;
+    if (!x_dev) return set_err(KNN_ERR_INVALID, "add: null pointer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->ntotal + n > 0xFFFFFFF0ll) return set_err(KNN_ERR_UNSUPPORTED, "add: more than 2^32 rows per index");
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    if (stream) HIP_TRY(hipStreamSynchronize(h->stream));
+    int rc = grow_index(h, h->ntotal + n);
+    if (rc) return rc;
+    rc = add_dev_impl(h, x_dev, n, s);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+extern "C" int knn_flat_add(knn_handle h, const float *x_host, int64_t n)
+{
+    if (!h) return set_err(KNN_ERR_INVALID, "add: null handle");
+    if (n < 0) return set_err(KNN_ERR_INVALID, "add: negative n");
+    if (n == 0) return 0;
+    if (!x_host) return set_err(KNN_ERR_INVALID, "add: null pointer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->ntotal + n > 0xFFFFFFF0ll) return set_err(KNN_ERR_UNSUPPORTED, "add: more than 2^32 rows per index");
+    int rc = grow_index(h, h->ntotal + n);
+    if (rc) return rc;
+    if (h->dp == h->d) {
+        float *dst = h->xb + (size_t)h->ntotal * h->dp;
+        HIP_TRY(hipMemcpy(dst, x_host, (size_t)n * h->d * 4, hipMemcpyHostToDevice));
+        rc = norms_dev_impl(dst, n, h->d, h->dp, h->yn + h->ntotal, h->stream);
+        if (rc) return rc;
+        h->ntotal += n;
+    } else {
+        const int64_t rows_per = std::max<int64_t>(1, (int64_t)(256ull << 20) / ((int64_t)h->d * 4));
+        if (h->ws_tmp.ensure((size_t)std::min(n, rows_per) * h->d * 4)) return set_err(KNN_ERR_HIP, "add: out of device memory");
+        for (int64_t i0 = 0; i0 < n; i0 += rows_per) {
+            int64_t m = std::min(rows_per, n - i0);
+            HIP_TRY(hipMemcpy(h->ws_tmp.p, x_host + i0 * h->d, (size_t)m * h->d * 4, hipMemcpyHostToDevice));
+            rc = add_dev_impl(h, (const float *)h->ws_tmp.p, m, h->stream);
+            if (rc) return rc;
+            HIP_TRY(hipStreamSynchronize(h->stream));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int knn_flat_reconstruct(knn_handle h, int64_t i0, int64_t n, float *out_host)
+{
+    if (!h) return set_err(KNN_ERR_INVALID, "reconstruct: null handle");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (i0 < 0 || n < 0 || i0 + n > h->ntotal) return set_err(KNN_ERR_INVALID, "reconstruct: range out of bounds");
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpy2D(out_host, (size_t)h->d * 4, h->xb + (size_t)i0 * h->dp, (size_t)h->dp * 4, (size_t)h->d * 4,
+                        (size_t)n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- search ---------------------------------------------------------------
+struct ScanPlan {
+    int qt, dt, nqtiles, nchunks, cap, grid;
+    int64_t chunk_rows;
+    size_t lds;
+    const char *name;
+};
+
+static int next_pow2_host(int n)
+{
+    int p = 64;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+template <int WM, int WN, int TM, int TN>
+static int launch_scan_cfg(const knn_index_s *h, const ScanParams &p, const ScanPlan &plan, hipStream_t s)
+{
+    const bool glds = !(h->flags & 1);
+    const bool l2 = h->metric == KNN_METRIC_L2;
+    void (*kern)(ScanParams) = nullptr;
+    if (l2)
+        kern = glds ? flat_scan_kernel<WM, WN, TM, TN, true, true> : flat_scan_kernel<WM, WN, TM, TN, true, false>;
+    else
+        kern = glds ? flat_scan_kernel<WM, WN, TM, TN, false, true> : flat_scan_kernel<WM, WN, TM, TN, false, false>;
+    HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds));
+    hipLaunchKernelGGL(kern, dim3(plan.grid), dim3(256), plan.lds, s, p);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static void make_plan(const knn_index_s *h, int64_t nq, int k, ScanPlan &pl)
+{
+    int qt = h->force_qt;
+    if (qt != 32 && qt != 64 && qt != 128) qt = nq <= 32 ? 32 : (nq <= 64 ? 64 : 128);
+    pl.qt = qt;
+    pl.dt = qt == 32 ? 256 : 128;
+    pl.name = qt == 128 ? "flat_scan_q128_d128" : (qt == 64 ? "flat_scan_q64_d128" : "flat_scan_q32_d256");
+    pl.nqtiles = (int)((nq + qt - 1) / qt);
+    pl.cap = next_pow2_host(2 * k + pl.dt);
+    if (pl.cap < 512) pl.cap = 512;
+    const int64_t ntiles = (h->ntotal + pl.dt - 1) / pl.dt;
+    int64_t want = h->force_chunks > 0 ? h->force_chunks : (1024 + pl.nqtiles - 1) / pl.nqtiles;
+    // each chunk should see enough rows to amortise its threshold warm-up
+    int64_t min_tiles = std::max<int64_t>(2, (4 * (int64_t)k + pl.dt - 1) / pl.dt);
+    if (h->force_chunks <= 0) want = std::min(want, std::max<int64_t>(1, ntiles / min_tiles));
+    want = std::max<int64_t>(1, std::min(want, ntiles));
+    // bound the candidate-list workspace (<= 2 GiB)
+    const size_t per_wg = (size_t)qt * pl.cap * 8;
+    int64_t max_wgs = std::max<int64_t>(pl.nqtiles, (int64_t)((2ull << 30) / per_wg));
+    want = std::max<int64_t>(1, std::min(want, max_wgs / pl.nqtiles));
+    int64_t tiles_per = (ntiles + want - 1) / want;
+    pl.chunk_rows = tiles_per * pl.dt;
+    pl.nchunks = (int)((h->ntotal + pl.chunk_rows - 1) / pl.chunk_rows);
+    pl.grid = pl.nqtiles * pl.nchunks;
+    pl.lds = (size_t)2 * (pl.dt + pl.qt) * 128 + (size_t)qt * 8 + 16;
+}
+
+// queries [nq][dp] already on device (padded); writes sorted keys [nq][k]
+static int search_keys_impl(knn_index_s *h, const float *q_dev, int64_t nq, int k, uint32_t id_base,
+                            uint64_t *keys_out, hipStream_t s)
+{
+    ScanPlan pl;
+    make_plan(h, nq, k, pl);
+    const float *xn = nullptr;
+    if (h->metric == KNN_METRIC_L2) {
+        if (h->ws_qn.ensure((size_t)nq * 4)) return set_err(KNN_ERR_HIP, "search: out of device memory");
+        int rc = norms_dev_impl(q_dev, nq, h->d, h->dp, (float *)h->ws_qn.p, s);
+        if (rc) return rc;
+        xn = (const float *)h->ws_qn.p;
+    }
+    if (h->ws_lists.ensure((size_t)pl.grid * pl.qt * pl.cap * 8) || h->ws_gthr.ensure((size_t)pl.nqtiles * pl.qt * 4))
+        return set_err(KNN_ERR_HIP, "search: out of device memory (candidate lists)");
+    uint64_t *partial = keys_out;
+    if (pl.nchunks > 1) {
+        if (h->ws_partial.ensure((size_t)nq * pl.nchunks * k * 8)) return set_err(KNN_ERR_HIP, "search: out of device memory");
+        partial = (uint64_t *)h->ws_partial.p;
+    }
+    HIP_TRY(hipMemsetAsync(h->ws_gthr.p, 0xFF, (size_t)pl.nqtiles * pl.qt * 4, s));
+    ScanParams p;
+    p.xb = h->xb; p.yn = h->yn; p.xq = q_dev; p.xn = xn;
+    p.nb = h->ntotal; p.nq = nq; p.dp = h->dp; p.k = k; p.cap = pl.cap;
+    p.nqtiles = pl.nqtiles; p.nchunks = pl.nchunks; p.chunk_rows = pl.chunk_rows;
+    p.lists = (uint64_t *)h->ws_lists.p; p.gthr = (uint32_t *)h->ws_gthr.p; p.partial = partial;
+    p.id_base = id_base;
+    HIP_TRY(hipEventRecord(h->ev0, s));
+    int rc;
+    if (pl.qt == 128) rc = launch_scan_cfg<2, 2, 2, 2>(h, p, pl, s);
+    else if (pl.qt == 64) rc = launch_scan_cfg<2, 2, 2, 1>(h, p, pl, s);
+    else rc = launch_scan_cfg<4, 1, 2, 1>(h, p, pl, s);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(h->ev1, s));
+    h->last_kernel = pl.name; h->last_qt = pl.qt; h->last_dt = pl.dt; h->last_chunks = pl.nchunks; h->last_grid = pl.grid;
+    // merge rounds
+    int L = pl.nchunks;
+    const uint64_t *in = partial;
+    bool flip = false;
+    while (L > 1) {
+        int G = std::max(2, 8192 / next_pow2_host(k));
+        int Lout = (L + G - 1) / G;
+        uint64_t *out;
+        if (Lout == 1) out = keys_out;
+        else {
+            DevBuf &b = flip ? h->ws_partial : h->ws_partial2;
+            if (b.ensure((size_t)nq * Lout * k * 8)) return set_err(KNN_ERR_HIP, "search: out of device memory");
+            out = (uint64_t *)b.p;
+        }
+        int n = std::min(L, G) * k;
+        size_t lds = (size_t)next_pow2_host(n) * 8;
+        HIP_TRY(hipFuncSetAttribute((const void *)merge_keys_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(merge_keys_kernel, dim3((unsigned)(nq * Lout)), dim3(256), lds, s, in, L, k, nq, 0, G, Lout, out);
+        HIP_TRY(hipGetLastError());
+        in = out;
+        L = Lout;
+        flip = !flip;
+    }
+    return 0;
+}
+
+static int check_search_args(knn_index_s *h, const void *q, int64_t nq, int64_t k, const void *D, const void *I)
+{
+    if (!h) return set_err(KNN_ERR_INVALID, "search: null handle");
+    if (nq < 0) return set_err(KNN_ERR_INVALID, "search: negative nq");
+    if (k < 1) return set_err(KNN_ERR_INVALID, "search: k must be >= 1");
+    if (k > KNN_MAX_K) return set_err(KNN_ERR_UNSUPPORTED, "search: k > 2048 is not supported by the fused top-k");
+    if (nq > 0 && (!q || !D || !I)) return set_err(KNN_ERR_INVALID, "search: null pointer");
+    return 0;
+}
+
+static int fill_empty(knn_index_s *h, float *D, int64_t *I, int64_t total, hipStream_t s)
+{
+    // index with no rows: every slot is unfilled
+    if (h->ws_keys.ensure((size_t)total * 8)) return set_err(KNN_ERR_HIP, "search: out of device memory");
+    HIP_TRY(hipMemsetAsync(h->ws_keys.p, 0xFF, (size_t)total * 8, s));
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                       (const uint64_t *)h->ws_keys.p, total, h->metric, D, I);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// q_dev: [nq][d] contiguous on device. D_dev/I_dev on device.
+static int search_dev_impl(knn_index_s *h, const float *q_dev, int64_t nq, int k, float *D_dev, int64_t *I_dev,
+                           uint64_t *keys_dev, uint32_t id_base, hipStream_t s)
+{
+    if (nq == 0) return 0;
+    const int64_t total = nq * k;
+    if (h->ntotal == 0) {
+        if (keys_dev) { HIP_TRY(hipMemsetAsync(keys_dev, 0xFF, (size_t)total * 8, s)); return 0; }
+        return fill_empty(h, D_dev, I_dev, total, s);
+    }
+    const float *qp = q_dev;
+    if (h->dp != h->d) {
+        if (h->ws_q.ensure((size_t)nq * h->dp * 4)) return set_err(KNN_ERR_HIP, "search: out of device memory");
+        int64_t tot = nq * h->dp;
+        unsigned grid = (unsigned)std::min<int64_t>((tot + 255) / 256, 65535);
+        hipLaunchKernelGGL(pad_rows_kernel, dim3(grid), dim3(256), 0, s, q_dev, nq, h->d, (float *)h->ws_q.p, h->dp);
+        HIP_TRY(hipGetLastError());
+        qp = (const float *)h->ws_q.p;
+    }
+    uint64_t *keys = keys_dev;
+    if (!keys) {
+        if (h->ws_keys.ensure((size_t)total * 8)) return set_err(KNN_ERR_HIP, "search: out of device memory");
+        keys = (uint64_t *)h->ws_keys.p;
+    }
+    int rc = search_keys_impl(h, qp, nq, k, id_base, keys, s);
+    if (rc) return rc;
+    if (!keys_dev) {
+        hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                           (const uint64_t *)keys, total, h->metric, D_dev, I_dev);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+extern "C" int knn_flat_search_dev(knn_handle h, const float *q_dev, int64_t nq, int64_t k, float *D_dev,
+                                   int64_t *I_dev, void *stream)
+{
+    int rc = check_search_args(h, q_dev, nq, k, D_dev, I_dev);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    rc = search_dev_impl(h, q_dev, nq, (int)k, D_dev, I_dev, nullptr, 0, s);
+    if (rc) return rc;
+    if (!stream) HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+extern "C" int knn_flat_search_keys_dev(knn_handle h, const float *q_dev, int64_t nq, int64_t k, uint32_t id_base,
+                                        uint64_t *keys_dev, void *stream)
+{
+    int rc = check_search_args(h, q_dev, nq, k, keys_dev, keys_dev);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    rc = search_dev_impl(h, q_dev, nq, (int)k, nullptr, nullptr, keys_dev, id_base, s);
+    if (rc) return rc;
+    if (!stream) HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+extern "C" int knn_merge_keys_dev(int32_t device, int32_t metric, const uint64_t *keys_dev, int32_t nlists,
+                                  int64_t nq, int64_t k, float *D_dev, int64_t *I_dev, void *stream)
+{
+    if (nlists < 1 || nq < 0 || k < 1 || k > KNN_MAX_K) return set_err(KNN_ERR_INVALID, "merge_keys: bad shape");
+    if (nq == 0) return 0;
+    int rc = ensure_device(device);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = nq * k;
+    const uint64_t *in = keys_dev;
+    uint64_t *bufs[2] = {nullptr, nullptr};
+    int L = nlists;
+    int list_major = 1;
+    int cur = 0;
+    auto cleanup = [&]() { for (auto b : bufs) if (b) (void)hipFree(b); };
+    while (L > 1) {
+        int G = std::max(2, 8192 / next_pow2_host((int)k));
+        int Lout = (L + G - 1) / G;
+        if (!bufs[cur]) {
+            if (hipMalloc((void **)&bufs[cur], (size_t)nq * Lout * k * 8) != hipSuccess) { cleanup(); return set_err(KNN_ERR_HIP, "merge_keys: out of device memory"); }
+        }
+        int n = std::min(L, G) * (int)k;
+        size_t lds = (size_t)next_pow2_host(n) * 8;
+        (void)hipFuncSetAttribute((const void *)merge_keys_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(merge_keys_kernel, dim3((unsigned)(nq * Lout)), dim3(256), lds, s, in, L, (int)k, nq,
+                           list_major, G, Lout, bufs[cur]);
+        if (hipGetLastError() != hipSuccess) { cleanup(); return set_err(KNN_ERR_HIP, "merge_keys: launch failed"); }
+        in = bufs[cur];
+        L = Lout;
+        list_major = 0;
+        cur ^= 1;
+    }
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, total, metric, D_dev, I_dev);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    cleanup();
+    if (e != hipSuccess) return set_err(KNN_ERR_HIP, std::string("merge_keys: ") + hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int knn_flat_search(knn_handle h, const float *q_host, int64_t nq, int64_t k, float *D_host,
+                               int64_t *I_host)
+{
+    int rc = check_search_args(h, q_host, nq, k, D_host, I_host);
+    if (rc) return rc;
+    if (nq == 0) return 0;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->device));
+    // query batches bound the device workspace; 16384 queries keep >= 128 query tiles in flight
+    const int64_t QB = 16384;
+    const int64_t bq = std::min(nq, QB);
+    if (h->ws_tmp2.ensure((size_t)bq * h->d * 4) || h->ws_D.ensure((size_t)bq * k * 4) || h->ws_I.ensure((size_t)bq * k * 8))
+        return set_err(KNN_ERR_HIP, "search: out of device memory");
+    float ms_total = 0.f;
+    for (int64_t b0 = 0; b0 < nq; b0 += QB) {
+        int64_t m = std::min(QB, nq - b0);
+        HIP_TRY(hipMemcpyAsync(h->ws_tmp2.p, q_host + b0 * h->d, (size_t)m * h->d * 4, hipMemcpyHostToDevice, h->stream));
+        rc = search_dev_impl(h, (const float *)h->ws_tmp2.p, m, (int)k, (float *)h->ws_D.p, (int64_t *)h->ws_I.p, nullptr, 0, h->stream);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(D_host + b0 * k, h->ws_D.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(I_host + b0 * k, h->ws_I.p, (size_t)m * k * 8, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (h->ntotal > 0) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) ms_total += ms;
+        }
+    }
+    h->last_ms = ms_total;
+    return 0;
+}
+
+extern "C" int knn_last_scan_info(knn_handle h, char *name, int32_t name_len, int32_t *query_tile, int32_t *db_tile,
+                                  int32_t *nchunks, int32_t *grid)
+{
+    if (!h) return set_err(KNN_ERR_INVALID, "null handle");
+    if (name && name_len > 0) {
+        strncpy(name, h->last_kernel.c_str(), (size_t)name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    if (query_tile) *query_tile = h->last_qt;
+    if (db_tile) *db_tile = h->last_dt;
+    if (nchunks) *nchunks = h->last_chunks;
+    if (grid) *grid = h->last_grid;
+    return 0;
+}
+
+extern "C" float knn_last_scan_ms(knn_handle h)
+{
+    if (!h) return -1.f;
+    std::lock_guard<std::mutex> lk(h->mu);
+    float ms = 0.f;
+    if (h->last_ms > 0.f) return h->last_ms;
+    if (hipEventElapsedTime(&ms, h->ev0, h->ev1) != hipSuccess) return -1.f;
+    return ms;
+}
+
+extern "C" int knn_set_tuning(knn_handle h, int32_t query_tile, int32_t nchunks, int32_t flags)
+{
+    if (!h) return set_err(KNN_ERR_INVALID, "null handle");
+    if (query_tile != 0 && query_tile != 32 && query_tile != 64 && query_tile != 128)
+        return set_err(KNN_ERR_INVALID, "set_tuning: query_tile must be 0, 32, 64 or 128");
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->force_qt = query_tile;
+    h->force_chunks = nchunks;
+    h->flags = flags;
+    return 0;
+}
+
+// ---- gather distances -------------------------------------------------------
+extern "C" int knn_gather_distances(knn_handle h, const float *q_host, int64_t nq, const int64_t *cand_ids,
+                                    const int64_t *cand_offsets, float *out_host)
+{
+    if (!h) return set_err(KNN_ERR_INVALID, "gather_distances: null handle");
+    if (nq < 0) return set_err(KNN_ERR_INVALID, "gather_distances: negative nq");
+    if (nq == 0) return 0;
+    if (!q_host || !cand_offsets) return set_err(KNN_ERR_INVALID, "gather_distances: null pointer");
+    const int64_t np = cand_offsets[nq];
+    if (np == 0) return 0;
+    if (!cand_ids || !out_host) return set_err(KNN_ERR_INVALID, "gather_distances: null pointer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->device));
+    std::vector<int32_t> pq((size_t)np);
+    for (int64_t i = 0; i < nq; i++) {
+        if (cand_offsets[i + 1] < cand_offsets[i]) return set_err(KNN_ERR_INVALID, "gather_distances: offsets not monotone");
+        for (int64_t p = cand_offsets[i]; p < cand_offsets[i + 1]; p++) {
+            if (cand_ids[p] < 0 || cand_ids[p] >= h->ntotal) return set_err(KNN_ERR_INVALID, "gather_distances: candidate id out of range");
+            pq[(size_t)p] = (int32_t)i;
+        }
+    }
+    hipStream_t s = h->stream;
+    if (h->ws_tmp2.ensure((size_t)nq * h->d * 4) || h->ws_q.ensure((size_t)nq * h->dp * 4) || h->ws_qn.ensure((size_t)nq * 4) ||
+        h->ws_I.ensure((size_t)np * 8) || h->ws_tmp.ensure((size_t)np * 4) || h->ws_D.ensure((size_t)np * 4))
+        return set_err(KNN_ERR_HIP, "gather_distances: out of device memory");
+    HIP_TRY(hipMemcpyAsync(h->ws_tmp2.p, q_host, (size_t)nq * h->d * 4, hipMemcpyHostToDevice, s));
+    {
+        int64_t tot = nq * h->dp;
+        unsigned grid = (unsigned)std::min<int64_t>((tot + 255) / 256, 65535);
+        hipLaunchKernelGGL(pad_rows_kernel, dim3(grid), dim3(256), 0, s, (const float *)h->ws_tmp2.p, nq, h->d, (float *)h->ws_q.p, h->dp);
+        HIP_TRY(hipGetLastError());
+    }
+    int rc = norms_dev_impl((const float *)h->ws_q.p, nq, h->d, h->dp, (float *)h->ws_qn.p, s);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(h->ws_I.p, cand_ids, (size_t)np * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(h->ws_tmp.p, pq.data(), (size_t)np * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(pair_distance_kernel, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, s, h->xb, h->yn,
+                       (const float *)h->ws_q.p, (const float *)h->ws_qn.p, h->dp, h->metric, np,
+                       (const int32_t *)h->ws_tmp.p, (const int64_t *)h->ws_I.p, (float *)h->ws_D.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_host, h->ws_D.p, (size_t)np * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}

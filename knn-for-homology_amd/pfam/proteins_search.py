@@ -1,0 +1,87 @@
+"""Drop-in for the reference's ``pfam/proteins_search.py`` (all-vs-all search over the
+Pfam full-sequence embeddings, k = 1000).
+
+Protocol kept from pfam/proteins_search.py:11-57:
+  argv[1] in {flat, lsh, hnsw} (anything else: ValueError(argv[1]));
+  ``full_sequences.npy`` is loaded, cast to float32 and L2-normalised in place;
+  flat  -> IndexFlat(d, METRIC_INNER_PRODUCT)
+  lsh   -> IndexLSH(d, 2048)
+  hnsw  -> IndexHNSWFlat(d, 42, METRIC_INNER_PRODUCT) with hnsw.efSearch = 256;
+  train + add, "Index creation took ..s", the index is written to
+  ``full_sequences_<mode>.index`` and the size line is printed, then a self-search with
+  k = 1000 is timed ("Search took ..s") and ``full_sequences_<mode>_{scores,hits}.npy``
+  are saved (float32 / int64, C order, plain ``numpy.save``).
+"""
+import sys
+from pathlib import Path
+from time import time
+from typing import Optional, Sequence
+
+import numpy
+
+from .. import faiss
+from ..paths import full_sequences_data as _default_dir
+
+K = 1000
+HNSW_M = 42
+HNSW_EF_SEARCH = 256
+LSH_BITS = 2048
+
+
+def naturalsize(nbytes: int) -> str:
+    """Decimal size string in the style the reference prints via ``humanize.naturalsize``
+    (pfam/proteins_search.py:41-45): 819200128 -> '819.2 MB'."""
+    sign = "-" if nbytes < 0 else ""
+    n = abs(int(nbytes))
+    if n == 1:
+        return f"{sign}1 Byte"
+    if n < 1000:
+        return f"{sign}{n} Bytes"
+    value = float(n)
+    for unit in ("kB", "MB", "GB", "TB", "PB", "EB", "ZB", "YB"):
+        value /= 1000.0
+        if value < 1000.0 or unit == "YB":
+            return f"{sign}{value:.1f} {unit}"
+
+
+def build_index(index_mode: str, d: int):
+    if index_mode == "flat":
+        return faiss.IndexFlat(d, faiss.METRIC_INNER_PRODUCT)
+    if index_mode == "lsh":
+        return faiss.IndexLSH(d, LSH_BITS)
+    if index_mode == "hnsw":
+        index = faiss.IndexHNSWFlat(d, HNSW_M, faiss.METRIC_INNER_PRODUCT)
+        index.hnsw.efSearch = HNSW_EF_SEARCH
+        return index
+    raise ValueError(index_mode)
+
+
+def main(argv: Optional[Sequence[str]] = None, data_dir: Optional[Path] = None, k: int = K):
+    argv = sys.argv if argv is None else argv
+    index_mode = argv[1]
+    data_dir = Path(data_dir) if data_dir is not None else _default_dir()
+    npy = data_dir / "full_sequences.npy"
+    embeddings = numpy.load(npy).astype(numpy.float32)
+    print("full_sequences", embeddings.shape)
+
+    started = time()
+    faiss.normalize_L2(embeddings)
+    index = build_index(index_mode, embeddings.shape[1])
+    index.train(embeddings)
+    index.add(embeddings)
+    print(f"Index creation took {int(time() - started)}s")
+    index_file = data_dir / f"full_sequences_{index_mode}.index"
+    faiss.write_index(index, str(index_file))
+    npy_size, index_size = npy.stat().st_size, index_file.stat().st_size
+    print(f"Embeddings: {naturalsize(npy_size)} Index: {naturalsize(index_size)} "
+          f"Difference: {naturalsize(index_size - npy_size)}")
+
+    started = time()
+    scores, hits = index.search(embeddings, k)
+    print(f"Search took {int(time() - started)}s")
+    numpy.save(data_dir / f"full_sequences_{index_mode}_scores.npy", scores)
+    numpy.save(data_dir / f"full_sequences_{index_mode}_hits.npy", hits)
+
+
+if __name__ == "__main__":
+    main()
