@@ -88,6 +88,9 @@ int knn_flat_search_keys_dev(knn_handle h, const float *q_dev, int64_t nq, int64
  * buffer) into final D/I on the given device */
 int knn_merge_keys_dev(int32_t device, int32_t metric, const uint64_t *keys_dev, int32_t nlists,
                        int64_t nq, int64_t k, float *D_dev, int64_t *I_dev, void *stream);
+/* pre-sizes the device storage for nrows rows (faiss has no equivalent; avoids
+ * regrowth copies when a shard is filled by several add calls) */
+int knn_flat_reserve(knn_handle h, int64_t nrows);
 /* index.ntotal / index.d / index.metric_type */
 int64_t knn_ntotal(knn_handle h);
 int32_t knn_dim(knn_handle h);
@@ -116,6 +119,10 @@ int knn_last_scan_info(knn_handle h, char *name, int32_t name_len, int32_t *quer
 /* device time (ms) of the scan kernel launches of the last search, measured
  * with hipEvents on the launch stream */
 float knn_last_scan_ms(knn_handle h);
+/* durations (ms) of the most recent scan launches (oldest first, at most 64 and at
+ * most max_n), each from a hipEvent pair recorded around the launch on the stream it
+ * was launched on; -1 for a launch that has not finished.  Returns the count. */
+int32_t knn_scan_times(knn_handle h, float *out_ms, int32_t max_n);
 /* force a scan configuration: query_tile in {0(auto),32,64,128}; nchunks 0=auto */
 int knn_set_tuning(knn_handle h, int32_t query_tile, int32_t nchunks, int32_t flags);
 

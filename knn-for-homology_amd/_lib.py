@@ -51,6 +51,8 @@ def _declare(L):
         "knn_last_scan_info": (c_int32, [H, c_char_p, c_int32, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
         "knn_last_scan_ms": (c_float, [H]),
         "knn_set_tuning": (c_int32, [H, c_int32, c_int32, c_int32]),
+        "knn_scan_times": (c_int32, [H, c_void_p, c_int32]),
+        "knn_flat_reserve": (c_int32, [H, c_int64]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here == the library does not export the ABI

@@ -9,7 +9,7 @@
 //   dot(x,y)  one fp32 fma chain per (query,row) pair, k visited per 8-block in
 //             the order 0,4,1,5,2,6,3,7 -- exactly what v_mfma_f32_32x32x2_f32
 //             produces when lane (i,h) feeds floats 8t+4h+m for m = 0..3
-//   nrm(x)    64 lane-partial fma chains + xor butterfly
+//   nrm(x)    dot(x, x): the same chain, so L2(x, x) == 0 exactly
 //   L2        max(0, fma(-2, dot, nrm(x)+nrm(y)))
 //   ties      lower row id first (packed 64-bit keys: score bits << 32 | row)
 //
@@ -56,86 +56,83 @@ __device__ __forceinline__ float ord2f(uint32_t o)
     return __uint_as_float(u);
 }
 
-__device__ __forceinline__ float wave_norm_row(const float *__restrict__ row, int d, int lane)
+// nrm(x) = dot(x, x) in the contract's chain order: one lane walks one row.
+template <bool ALIGNED>
+__device__ __forceinline__ float lane_norm_row(const float *__restrict__ r, int d)
 {
     float acc = 0.0f;
-    for (int e0 = 0; e0 < d; e0 += 256) {
-        int e = e0 + 4 * lane;
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-        if (e + 3 < d) {
-            f32x4 v = *(const f32x4 *)(row + e);
-            v0 = v[0]; v1 = v[1]; v2 = v[2]; v3 = v[3];
+    int k0 = 0;
+    for (; k0 + 8 <= d; k0 += 8) {
+        float a[8];
+        if constexpr (ALIGNED) {
+            f32x4 lo = *(const f32x4 *)(r + k0), hi = *(const f32x4 *)(r + k0 + 4);
+#pragma unroll
+            for (int m = 0; m < 4; m++) { a[m] = lo[m]; a[4 + m] = hi[m]; }
         } else {
-            if (e < d) v0 = row[e];
-            if (e + 1 < d) v1 = row[e + 1];
-            if (e + 2 < d) v2 = row[e + 2];
+#pragma unroll
+            for (int m = 0; m < 8; m++) a[m] = r[k0 + m];
         }
-        acc = __builtin_fmaf(v0, v0, acc);
-        acc = __builtin_fmaf(v1, v1, acc);
-        acc = __builtin_fmaf(v2, v2, acc);
-        acc = __builtin_fmaf(v3, v3, acc);
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            acc = __builtin_fmaf(a[m], a[m], acc);
+            acc = __builtin_fmaf(a[4 + m], a[4 + m], acc);
+        }
     }
-    for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off, 64);
+    if (k0 < d) {
+        float a[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) a[m] = (k0 + m < d) ? r[k0 + m] : 0.0f;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            acc = __builtin_fmaf(a[m], a[m], acc);
+            acc = __builtin_fmaf(a[4 + m], a[4 + m], acc);
+        }
+    }
     return acc;
 }
 
-// rows must be 16-byte aligned when d % 4 == 0 (stride multiple of 4 floats)
-__global__ void norm_rows_kernel(const float *__restrict__ x, int64_t n, int d, int64_t stride,
-                                 float *__restrict__ out)
+// one lane per row; 64-thread blocks
+template <bool ALIGNED>
+__global__ __launch_bounds__(64) void norm_rows_kernel(const float *__restrict__ x, int64_t n, int d, int64_t stride,
+                                                        float *__restrict__ out)
 {
-    int lane = threadIdx.x & 63;
-    int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int64_t row = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (row >= n) return;
-    float nr = wave_norm_row(x + row * stride, d, lane);
-    if (lane == 0) out[row] = nr;
+    out[row] = lane_norm_row<ALIGNED>(x + row * stride, d);
 }
 
-__global__ void normalize_rows_kernel(float *__restrict__ x, int64_t n, int d, int64_t stride)
+// faiss.normalize_L2: each lane computes the norm of its own row, then the wave
+// rescales the block's 64 rows one after the other with coalesced accesses.
+template <bool ALIGNED>
+__global__ __launch_bounds__(64) void normalize_rows_kernel(float *__restrict__ x, int64_t n, int d, int64_t stride)
 {
-    int lane = threadIdx.x & 63;
-    int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= n) return;
-    float *r = x + row * stride;
-    float nr = wave_norm_row(r, d, lane);
-    if (nr > 0.0f) {
-        const float inv = (float)(1.0 / (double)__fsqrt_rn(nr));
-        for (int e0 = 0; e0 < d; e0 += 256) {
-            int e = e0 + 4 * lane;
-            if (e + 3 < d) {
-                f32x4 v = *(f32x4 *)(r + e);
-                v[0] *= inv; v[1] *= inv; v[2] *= inv; v[3] *= inv;
-                *(f32x4 *)(r + e) = v;
-            } else {
-                for (int c = 0; c < 3; c++)
-                    if (e + c < d) r[e + c] *= inv;
+    const int lane = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    const int64_t row = row0 + lane;
+    float inv = 0.0f; // 0 == leave the row alone
+    if (row < n) {
+        float nr = lane_norm_row<ALIGNED>(x + row * stride, d);
+        if (nr > 0.0f) inv = (float)(1.0 / (double)sqrtf(nr));
+    }
+    const int nrows = (int)min((int64_t)64, n - row0);
+    for (int r = 0; r < nrows; r++) {
+        const float s = __shfl(inv, r, 64);
+        if (s == 0.0f) continue;
+        float *p = x + (row0 + r) * stride;
+        if constexpr (ALIGNED) {
+            for (int e = 4 * lane; e < d; e += 256) {
+                if (e + 3 < d) {
+                    f32x4 v = *(f32x4 *)(p + e);
+                    v[0] *= s; v[1] *= s; v[2] *= s; v[3] *= s;
+                    *(f32x4 *)(p + e) = v;
+                } else {
+                    for (int c = 0; c < 3; c++)
+                        if (e + c < d) p[e + c] *= s;
+                }
             }
+        } else {
+            for (int e = lane; e < d; e += 64) p[e] *= s;
         }
-    }
-}
-
-// scalar-path variants for rows that are not 16-byte aligned (d % 4 != 0)
-__global__ void norm_rows_unaligned_kernel(const float *__restrict__ x, int64_t n, int d,
-                                           int64_t stride, float *__restrict__ out, int normalize,
-                                           float *__restrict__ xw)
-{
-    int lane = threadIdx.x & 63;
-    int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= n) return;
-    const float *r = x + row * stride;
-    float acc = 0.0f;
-    for (int e0 = 0; e0 < d; e0 += 256) {
-        for (int c = 0; c < 4; c++) {
-            int e = e0 + 4 * lane + c;
-            float v = e < d ? r[e] : 0.0f;
-            acc = __builtin_fmaf(v, v, acc);
-        }
-    }
-    for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off, 64);
-    if (out && lane == 0) out[row] = acc;
-    if (normalize && acc > 0.0f) {
-        const float inv = (float)(1.0 / (double)__fsqrt_rn(acc));
-        float *w = xw + row * stride;
-        for (int e = lane; e < d; e += 64) w[e] *= inv;
     }
 }
 
@@ -223,7 +220,8 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *stage0 = smem;
     char *stage1 = smem + STAGE_BYTES;
-    float *s_thr = (float *)(smem + 2 * STAGE_BYTES);
+    const int lds_main = max(2 * STAGE_BYTES, p.cap * 8);
+    float *s_thr = (float *)(smem + lds_main);
     int *s_cnt = (int *)(s_thr + QT);
     int *s_need = s_cnt + QT;
 
@@ -545,7 +543,10 @@ struct knn_index_s {
     float *xb = nullptr; // [cap_rows][dp]
     float *yn = nullptr; // [cap_rows + pad]
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr; // the pair of the most recent scan launch
+    static const int RING = 64;
+    hipEvent_t ring0[RING] = {nullptr}, ring1[RING] = {nullptr};
+    int64_t nlaunches = 0;
     std::mutex mu;
     DevBuf ws_q, ws_qn, ws_lists, ws_gthr, ws_partial, ws_partial2, ws_keys, ws_D, ws_I, ws_tmp, ws_tmp2;
     // tuning + introspection
@@ -587,26 +588,22 @@ static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static int normalize_dev_impl(float *x, int64_t n, int d, int64_t stride, hipStream_t s)
 {
     if (n == 0) return 0;
-    const int wpb = 4;
-    unsigned grid = (unsigned)((n + wpb - 1) / wpb);
+    unsigned grid = (unsigned)((n + 63) / 64);
     if ((stride % 4) == 0 && (((uintptr_t)x) % 16) == 0)
-        hipLaunchKernelGGL(normalize_rows_kernel, dim3(grid), dim3(64 * wpb), 0, s, x, n, d, stride);
+        hipLaunchKernelGGL(normalize_rows_kernel<true>, dim3(grid), dim3(64), 0, s, x, n, d, stride);
     else
-        hipLaunchKernelGGL(norm_rows_unaligned_kernel, dim3(grid), dim3(64 * wpb), 0, s, x, n, d, stride,
-                           (float *)nullptr, 1, x);
+        hipLaunchKernelGGL(normalize_rows_kernel<false>, dim3(grid), dim3(64), 0, s, x, n, d, stride);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 static int norms_dev_impl(const float *x, int64_t n, int d, int64_t stride, float *out, hipStream_t s)
 {
     if (n == 0) return 0;
-    const int wpb = 4;
-    unsigned grid = (unsigned)((n + wpb - 1) / wpb);
+    unsigned grid = (unsigned)((n + 63) / 64);
     if ((stride % 4) == 0 && (((uintptr_t)x) % 16) == 0)
-        hipLaunchKernelGGL(norm_rows_kernel, dim3(grid), dim3(64 * wpb), 0, s, x, n, d, stride, out);
+        hipLaunchKernelGGL(norm_rows_kernel<true>, dim3(grid), dim3(64), 0, s, x, n, d, stride, out);
     else
-        hipLaunchKernelGGL(norm_rows_unaligned_kernel, dim3(grid), dim3(64 * wpb), 0, s, x, n, d, stride, out,
-                           0, (float *)nullptr);
+        hipLaunchKernelGGL(norm_rows_kernel<false>, dim3(grid), dim3(64), 0, s, x, n, d, stride, out);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -663,10 +660,9 @@ extern "C" int knn_flat_create(int32_t d, int32_t metric, knn_handle *out)
     h->dp = round_up(d, 32);
     h->metric = metric;
     h->device = g_device;
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
-        return set_err(KNN_ERR_HIP, "flat_create: stream/event creation failed");
+        return set_err(KNN_ERR_HIP, "flat_create: stream creation failed");
     }
     *out = h;
     return 0;
@@ -690,8 +686,10 @@ extern "C" void knn_free(knn_handle h)
         DevBuf *bufs[] = {&h->ws_q, &h->ws_qn, &h->ws_lists, &h->ws_gthr, &h->ws_partial, &h->ws_partial2,
                           &h->ws_keys, &h->ws_D, &h->ws_I, &h->ws_tmp, &h->ws_tmp2};
         for (DevBuf *b : bufs) b->release();
-        if (h->ev0) (void)hipEventDestroy(h->ev0);
-        if (h->ev1) (void)hipEventDestroy(h->ev1);
+        for (int i = 0; i < knn_index_s::RING; i++) {
+            if (h->ring0[i]) (void)hipEventDestroy(h->ring0[i]);
+            if (h->ring1[i]) (void)hipEventDestroy(h->ring1[i]);
+        }
         if (h->stream) (void)hipStreamDestroy(h->stream);
     }
     delete h;
@@ -876,7 +874,7 @@ static void make_plan(const knn_index_s *h, int64_t nq, int k, ScanPlan &pl)
     pl.chunk_rows = tiles_per * pl.dt;
     pl.nchunks = (int)((h->ntotal + pl.chunk_rows - 1) / pl.chunk_rows);
     pl.grid = pl.nqtiles * pl.nchunks;
-    pl.lds = (size_t)2 * (pl.dt + pl.qt) * 128 + (size_t)qt * 8 + 16;
+    pl.lds = std::max((size_t)2 * (pl.dt + pl.qt) * 128, (size_t)pl.cap * 8) + (size_t)qt * 8 + 16;
 }
 
 // queries [nq][dp] already on device (padded); writes sorted keys [nq][k]
@@ -906,6 +904,16 @@ static int search_keys_impl(knn_index_s *h, const float *q_dev, int64_t nq, int 
     p.nqtiles = pl.nqtiles; p.nchunks = pl.nchunks; p.chunk_rows = pl.chunk_rows;
     p.lists = (uint64_t *)h->ws_lists.p; p.gthr = (uint32_t *)h->ws_gthr.p; p.partial = partial;
     p.id_base = id_base;
+    {
+        const int slot = (int)(h->nlaunches % knn_index_s::RING);
+        if (!h->ring0[slot]) {
+            HIP_TRY(hipEventCreate(&h->ring0[slot]));
+            HIP_TRY(hipEventCreate(&h->ring1[slot]));
+        }
+        h->ev0 = h->ring0[slot];
+        h->ev1 = h->ring1[slot];
+        h->nlaunches++;
+    }
     HIP_TRY(hipEventRecord(h->ev0, s));
     int rc;
     if (pl.qt == 128) rc = launch_scan_cfg<2, 2, 2, 2>(h, p, pl, s);
@@ -1003,6 +1011,7 @@ extern "C" int knn_flat_search_dev(knn_handle h, const float *q_dev, int64_t nq,
     std::lock_guard<std::mutex> lk(h->mu);
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    h->last_ms = -1.f;
     rc = search_dev_impl(h, q_dev, nq, (int)k, D_dev, I_dev, nullptr, 0, s);
     if (rc) return rc;
     if (!stream) HIP_TRY(hipStreamSynchronize(s));
@@ -1017,6 +1026,7 @@ extern "C" int knn_flat_search_keys_dev(knn_handle h, const float *q_dev, int64_
     std::lock_guard<std::mutex> lk(h->mu);
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    h->last_ms = -1.f;
     rc = search_dev_impl(h, q_dev, nq, (int)k, nullptr, nullptr, keys_dev, id_base, s);
     if (rc) return rc;
     if (!stream) HIP_TRY(hipStreamSynchronize(s));
@@ -1085,7 +1095,7 @@ extern "C" int knn_flat_search(knn_handle h, const float *q_host, int64_t nq, in
         HIP_TRY(hipMemcpyAsync(D_host + b0 * k, h->ws_D.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipMemcpyAsync(I_host + b0 * k, h->ws_I.p, (size_t)m * k * 8, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
-        if (h->ntotal > 0) {
+        if (h->ntotal > 0 && h->ev0) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) ms_total += ms;
         }
@@ -1114,9 +1124,57 @@ extern "C" float knn_last_scan_ms(knn_handle h)
     if (!h) return -1.f;
     std::lock_guard<std::mutex> lk(h->mu);
     float ms = 0.f;
-    if (h->last_ms > 0.f) return h->last_ms;
-    if (hipEventElapsedTime(&ms, h->ev0, h->ev1) != hipSuccess) return -1.f;
+    if (h->last_ms >= 0.f) return h->last_ms;
+    if (!h->ev0 || hipEventElapsedTime(&ms, h->ev0, h->ev1) != hipSuccess) return -1.f;
     return ms;
+}
+
+extern "C" int32_t knn_scan_times(knn_handle h, float *out_ms, int32_t max_n)
+{
+    if (!h || !out_ms || max_n < 0) return set_err(KNN_ERR_INVALID, "scan_times: bad arguments");
+    std::lock_guard<std::mutex> lk(h->mu);
+    int64_t n = std::min<int64_t>(std::min<int64_t>(h->nlaunches, knn_index_s::RING), max_n);
+    // oldest first among the n most recent launches; launches whose events have not completed read -1
+    for (int64_t i = 0; i < n; i++) {
+        int64_t idx = h->nlaunches - n + i;
+        int slot = (int)(idx % knn_index_s::RING);
+        float ms = -1.f;
+        if (hipEventElapsedTime(&ms, h->ring0[slot], h->ring1[slot]) != hipSuccess) ms = -1.f;
+        out_ms[i] = ms;
+    }
+    return (int32_t)n;
+}
+
+extern "C" int knn_flat_reserve(knn_handle h, int64_t nrows)
+{
+    if (!h) return set_err(KNN_ERR_INVALID, "reserve: null handle");
+    if (nrows < 0 || nrows > 0xFFFFFFF0ll) return set_err(KNN_ERR_INVALID, "reserve: bad row count");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->device));
+    if (nrows <= h->cap_rows) return 0;
+    // exact-size allocation (grow_index only over-allocates when it has to guess)
+    int64_t keep = h->cap_rows;
+    h->cap_rows = 0;
+    int64_t saved_total = h->ntotal;
+    if (saved_total > 0) { h->cap_rows = keep; }
+    float *nxb = nullptr, *nyn = nullptr;
+    size_t row_bytes = (size_t)h->dp * 4;
+    HIP_TRY(hipMalloc((void **)&nxb, (size_t)nrows * row_bytes));
+    if (hipMalloc((void **)&nyn, ((size_t)nrows + 64) * 4) != hipSuccess) {
+        (void)hipFree(nxb);
+        return set_err(KNN_ERR_HIP, "reserve: out of device memory");
+    }
+    if (saved_total > 0) {
+        HIP_TRY(hipMemcpyAsync(nxb, h->xb, (size_t)saved_total * row_bytes, hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(nyn, h->yn, (size_t)saved_total * 4, hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    if (h->xb) (void)hipFree(h->xb);
+    if (h->yn) (void)hipFree(h->yn);
+    h->xb = nxb;
+    h->yn = nyn;
+    h->cap_rows = nrows;
+    return 0;
 }
 
 extern "C" int knn_set_tuning(knn_handle h, int32_t query_tile, int32_t nchunks, int32_t flags)

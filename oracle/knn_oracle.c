@@ -38,9 +38,7 @@
  * multiply-add, no wider accumulator:
  *   dot(x,y):  acc = 0; for each block of 8 consecutive k (zero padded),
  *              in the order 0,4,1,5,2,6,3,7:  acc = fmaf(x[k], y[k], acc)
- *   nrm(x):    64 partial chains  p[l] = fmaf(x[e], x[e], p[l]) over
- *              e = 256*i + 4*l + c  (i outer, c = 0..3 inner, zero padded),
- *              then p[l] += p[l ^ off] for off = 32,16,8,4,2,1
+ *   nrm(x):    dot(x, x) -- the same chain, so L2(x, x) is exactly 0
  *   L2(x,y):   t = nrm(x) + nrm(y);  s = fmaf(-2, dot(x,y), t);  max(s, 0)
  *   ties:      equal scores are ordered by ascending database row id
  * The HIP kernels are written to produce exactly these bits, so GPU results
@@ -74,27 +72,9 @@ float orc_dot(const float *x, const float *y, int d)
     return acc;
 }
 
-float orc_norm_one(const float *x, int d)
-{
-    float p[64];
-    int nblk = (d + 255) / 256;
-    for (int l = 0; l < 64; l++) {
-        float acc = 0.0f;
-        for (int i = 0; i < nblk; i++)
-            for (int c = 0; c < 4; c++) {
-                int e = 256 * i + 4 * l + c;
-                float v = e < d ? x[e] : 0.0f;
-                acc = fmaf(v, v, acc);
-            }
-        p[l] = acc;
-    }
-    for (int off = 32; off >= 1; off >>= 1) {
-        float q[64];
-        for (int l = 0; l < 64; l++) q[l] = p[l] + p[l ^ off];
-        memcpy(p, q, sizeof p);
-    }
-    return p[0];
-}
+/* nrm(x) is by definition dot(x, x): the same chain, so an L2 self distance
+ * nrm(x)+nrm(x)-2*dot(x,x) is exactly 0 */
+float orc_norm_one(const float *x, int d) { return orc_dot(x, x, d); }
 
 void orc_norm_l2sqr(const float *x, int64_t n, int d, float *out)
 {
@@ -221,7 +201,7 @@ int orc_flat_search(const float *xb, int64_t nb, const float *xq, int64_t nq, in
                     int64_t row = b * RB + r;
                     if (row >= nb) break;
                     float v = score_to_v(metric, acc[r], xn ? xn[qi] : 0.0f, yn ? yn[row] : 0.0f);
-                    if (v != v) continue; /* NaN never becomes a hit */
+                    if (!(v < INFINITY)) continue; /* NaN / +inf ("worse than everything") never becomes a hit */
                     uint64_t key = ((uint64_t)f2ord(v) << 32) | (uint32_t)row;
                     if (hn < k) {
                         heap[hn++] = key;

@@ -137,19 +137,21 @@ def exact_knn_f64(xb, xq, k, metric):
     return np.take_along_axis(s, order, 1), order.astype(np.int64)
 
 
-def compare_tie_tolerant(I_got, D_got, xb, xq, metric, tau_rel=8e-6, dist_atol=1e-5):
+def compare_tie_tolerant(I_got, D_got, xb, xq, metric, tau_rel=8e-6, dist_rtol=1e-5):
     """Check an fp32 (D, I) result against the fp64 truth.
 
     An fp32 result is accepted iff, per query,
       * every returned id's TRUE (fp64) score is within ``tau`` of the true score
         at the same rank (so ids may only be permuted inside a cluster of
         near-ties, or swapped across the k-boundary with a near-tied candidate),
-      * returned distances are within ``dist_atol * max(1, |score|)`` of the true
-        score of the returned id,
+      * returned distances are within ``dist_rtol * scale`` of the true score of the
+        returned id, scale = max(1, |x||y|) for inner product and
+        max(1, |x|^2 + |y|^2) for squared L2 (the magnitudes the fp32 sum is formed
+        from; for unit-norm cosine this is the north-star's absolute 1e-5),
       * no id is returned twice.
-    tau = tau_rel * sqrt(d) * (||x|| * ||y||) bounds fp32 summation-order noise
-    (probabilistic form).  Returns a dict of counts; raises
-    AssertionError on violation.
+    tau = tau_rel * sqrt(d) * scale bounds fp32 summation-order noise (SURVEY.md 7.3
+    H1, probabilistic form).  Returns a dict of counts; raises AssertionError on
+    violation.
     """
     I_got = np.asarray(I_got)
     D_got = np.asarray(D_got, np.float64)
@@ -159,26 +161,28 @@ def compare_tie_tolerant(I_got, D_got, xb, xq, metric, tau_rel=8e-6, dist_atol=1
     kk = min(k, nb)
     D_true, I_true = exact_knn_f64(xb, xq, kk, metric)
     d = np.asarray(xb).shape[1]
-    bn = np.sqrt((np.asarray(xb, np.float64) ** 2).sum(1))
-    qn = np.sqrt((np.asarray(xq, np.float64) ** 2).sum(1))
-    scale = qn[:, None] * (bn.max() if nb else 1.0)
-    if metric == METRIC_L2:
-        scale = (qn[:, None] + (bn.max() if nb else 0.0)) ** 2
-    tau = tau_rel * np.sqrt(d) * np.maximum(scale, 1e-30)
     got = I_got[:, :kk]
     assert (got >= 0).all() and (got < nb).all(), "id out of range"
+    bn2 = (np.asarray(xb, np.float64) ** 2).sum(1)
+    qn2 = (np.asarray(xq, np.float64) ** 2).sum(1)
+    if metric == METRIC_INNER_PRODUCT:
+        scale = np.maximum(1.0, np.sqrt(qn2)[:, None] * np.sqrt(bn2)[got])
+        scale_max = np.maximum(1.0, np.sqrt(qn2)[:, None] * np.sqrt(bn2.max(initial=0.0)))
+    else:
+        scale = np.maximum(1.0, qn2[:, None] + bn2[got])
+        scale_max = np.maximum(1.0, qn2[:, None] + bn2.max(initial=0.0))
+    tau = tau_rel * np.sqrt(d) * scale_max
     srt = np.sort(got, axis=1)
     assert (srt[:, 1:] != srt[:, :-1]).all(), "duplicate ids in a result row"
     true_of_got = np.take_along_axis(s, got, 1)
     rank_err = np.abs(true_of_got - D_true)
     assert (rank_err <= tau).all(), f"rank error {rank_err.max()} exceeds tau {tau.min()}"
     derr = np.abs(D_got[:, :kk] - true_of_got)
-    tol = dist_atol * np.maximum(1.0, np.abs(true_of_got))
-    assert (derr <= tol).all(), f"distance error {derr.max()}"
+    assert (derr <= dist_rtol * scale).all(), f"distance error {(derr / scale).max()} (relative to scale)"
     if k > kk:
         assert (I_got[:, kk:] == -1).all(), "unfilled slots must be id -1"
     return {"permuted": int((got != I_true).sum()), "max_rank_err": float(rank_err.max(initial=0.0)),
-            "max_dist_err": float(derr.max(initial=0.0))}
+            "max_dist_err_rel": float((derr / scale).max(initial=0.0))}
 
 
 def recall_at_k(I_got, I_true):

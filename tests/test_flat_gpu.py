@@ -1,0 +1,306 @@
+"""GPU parity tests (run with -m gpu on an MI355X): everything goes through the C ABI of
+libknn355.so (via the faiss-shaped facade) and is compared BIT FOR BIT -- neighbour ids
+and float32 distances -- with the CPU oracle, with the committed golden vectors, and
+with the reference's own known answers."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, DATASETS
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(ds):
+    return np.load(GOLDEN / ds / "train.npy"), np.load(GOLDEN / ds / "test.npy")
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def _assert_same(D, I, Do, Io):
+    assert np.array_equal(I, Io), f"{int((I != Io).sum())} neighbour ids differ"
+    assert np.array_equal(_bits(D), _bits(Do)), f"{int((_bits(D) != _bits(Do)).sum())} distances differ"
+
+
+# ---- the reference's own tests, read through the drop-in entry points -------------
+def test_search_ann(gpu_faiss):
+    """tests/test_main.py:10-18 of the reference."""
+    from knn_for_homology_amd.seqvec_search.data import LoadedData
+    from knn_for_homology_amd.seqvec_search.main import faiss_search, evaluate_faiss
+    data = LoadedData.from_options(path=GOLDEN / "small-random", hits=5)
+    queries = np.load(str(data.test))
+    results, scores, search_time = faiss_search(np.load(str(data.train)), queries, data.hits)
+    auc1s, tps = evaluate_faiss(data, results)
+    assert auc1s == [1.0, 1 / 3, 2 / 3, 0.0, 0.0, 1 / 3]
+    assert tps == [1.0, 2 / 3, 2 / 3, 1.0, 1.0, 1.0]
+    assert results.dtype == np.int64 and scores.dtype == np.float32 and search_time >= 0
+
+
+def test_ann_alignment_knn_half(gpu_faiss):
+    """tests/test_main.py:21-27 of the reference (the MMseqs2 half needs the external binary)."""
+    from knn_for_homology_amd.seqvec_search.data import LoadedData
+    from knn_for_homology_amd.seqvec_search.main import faiss_search, evaluate_faiss
+    data = LoadedData.from_options(path=GOLDEN / "pfam-20-10", hits=10)
+    queries = np.load(str(data.test))
+    results, scores, _ = faiss_search(np.load(str(data.train)), queries, data.hits)
+    auc1s_ann, tps_ann = evaluate_faiss(data, results)
+    assert np.mean(auc1s_ann) == 0.871
+    assert np.mean(tps_ann) == 0.91
+
+
+def test_faiss_search_matches_reference_driven_vectors(gpu_faiss):
+    """ids / scores / in-place normalisation equal what the REFERENCE's faiss_search
+    produced when driving the oracle (tests/golden/reference_driven.npz)."""
+    from knn_for_homology_amd.seqvec_search.main import faiss_search
+    g = np.load(GOLDEN / "reference_driven.npz")
+    for ds, k in (("small-random", 5), ("pfam-20-10", 10)):
+        key = ds.replace("-", "_")
+        hay, qs = _load(ds)
+        ids, scores, _ = faiss_search(hay, qs, k)
+        assert np.array_equal(hay, g[f"{key}_haystack_after"]), "haystack must be normalised in place"
+        assert np.array_equal(qs, g[f"{key}_queries_after"]), "queries must be normalised in place"
+        _assert_same(scores, ids, g[f"{key}_scores"], g[f"{key}_ids"])
+
+
+# ---- golden vectors ----------------------------------------------------------------
+@pytest.mark.parametrize("ds", DATASETS)
+def test_golden_vectors(gpu_faiss, ds):
+    g = np.load(GOLDEN / f"oracle_{ds}.npz")
+    train, test = _load(ds)
+    tn, qn = train.copy(), test.copy()
+    gpu_faiss.normalize_L2(tn)
+    gpu_faiss.normalize_L2(qn)
+    if "train_normalized" in g:
+        assert np.array_equal(tn, g["train_normalized"]) and np.array_equal(qn, g["test_normalized"])
+    ip = gpu_faiss.IndexFlat(train.shape[1], gpu_faiss.METRIC_INNER_PRODUCT)
+    ip.add(tn)
+    l2 = gpu_faiss.IndexFlat(train.shape[1], gpu_faiss.METRIC_L2)
+    l2.add(train)
+    assert ip.ntotal == train.shape[0] and ip.d == 1024
+    for k in (5, 10, 11, 13, 100, 1000):
+        k = min(k, train.shape[0])
+        D, I = ip.search(qn, k)
+        _assert_same(D, I, g[f"ip_k{k}_D"], g[f"ip_k{k}_I"])
+        D, I = l2.search(test, k)
+        _assert_same(D, I, g[f"l2_k{k}_D"], g[f"l2_k{k}_I"])
+
+
+@pytest.mark.parametrize("ds", DATASETS)
+def test_cath_search_semantics(gpu_faiss, ds):
+    """cath/search.py:13-26: self hit stripped, (hits, scores) order, input untouched."""
+    from knn_for_homology_amd.cath.search import search
+    g = np.load(GOLDEN / f"oracle_{ds}.npz")
+    train, _ = _load(ds)
+    before = train.copy()
+    hits, scores = search(train, hits=10, metric=gpu_faiss.METRIC_INNER_PRODUCT)
+    assert np.array_equal(train, before), "cosine search must normalise a copy"
+    assert hits.shape == (train.shape[0], 10) and hits.dtype == np.int64 and scores.dtype == np.float32
+    _assert_same(scores, hits, g["self_ip_k11_D"][:, 1:], g["self_ip_k11_I"][:, 1:])
+    hits, scores = search(train, hits=10, metric=gpu_faiss.METRIC_L2)
+    assert np.array_equal(train, before)
+    _assert_same(scores, hits, g["self_l2_k11_D"][:, 1:], g["self_l2_k11_I"][:, 1:])
+    # the stripped column is the self hit, at distance exactly 0 (nrm(x) == dot(x, x))
+    idx = gpu_faiss.IndexFlat(1024, gpu_faiss.METRIC_L2)
+    idx.add(train)
+    D, I = idx.search(train, 1)
+    assert (I[:, 0] == np.arange(train.shape[0])).all() and (D == 0).all()
+
+
+# ---- synthetic shapes against the live oracle ---------------------------------------
+CASES = [
+    # nq, nb, d, k, query_tile, nchunks
+    (1, 1000, 1024, 10, 0, 0),
+    (7, 5000, 1024, 1, 0, 0),
+    (37, 5000, 1024, 100, 32, 1),
+    (37, 5000, 1024, 100, 32, 3),
+    (69, 5000, 1024, 100, 64, 1),
+    (69, 5000, 1024, 100, 64, 5),
+    (133, 5000, 1024, 100, 128, 1),
+    (133, 5000, 1024, 100, 128, 3),
+    (300, 5000, 1024, 301, 0, 0),
+    (300, 5000, 1024, 1000, 0, 0),
+    (40, 5000, 1024, 2048, 0, 0),
+    (77, 2049, 100, 13, 0, 0),
+    (50, 700, 37, 11, 0, 0),
+    (260, 4100, 128, 64, 0, 0),
+    (32, 60000, 1024, 100, 0, 0),
+]
+
+
+@pytest.mark.parametrize("nq,nb,d,k,qt,nch", CASES)
+@pytest.mark.parametrize("metric", [0, 1])
+def test_random_vs_oracle(gpu_faiss, oracle, nq, nb, d, k, qt, nch, metric):
+    rng = np.random.default_rng(nq * 7919 + nb + d + k)
+    xb = rng.standard_normal((nb, d), dtype=np.float32)
+    xq = rng.standard_normal((nq, d), dtype=np.float32)
+    idx = gpu_faiss.IndexFlat(d, metric)
+    idx.set_tuning(qt, nch, 0)
+    idx.add(xb)
+    D, I = idx.search(xq, k)
+    Do, Io = oracle.flat_search(xb, xq, k, metric)
+    _assert_same(D, I, Do, Io)
+
+
+def test_register_staged_variant_matches(gpu_faiss, oracle):
+    """flags=1 selects the register-staged (no LDS-DMA) build of the scan kernel."""
+    rng = np.random.default_rng(5)
+    xb = rng.standard_normal((3000, 1024), dtype=np.float32)
+    xq = rng.standard_normal((150, 1024), dtype=np.float32)
+    for metric in (0, 1):
+        idx = gpu_faiss.IndexFlat(1024, metric)
+        idx.set_tuning(0, 0, 1)
+        idx.add(xb)
+        _assert_same(*idx.search(xq, 50), *oracle.flat_search(xb, xq, 50, metric))
+
+
+def test_normalize_matches_oracle(gpu_faiss, oracle):
+    rng = np.random.default_rng(11)
+    for n, d in ((1000, 1024), (333, 100), (50, 37), (1, 1024), (129, 8)):
+        x = rng.standard_normal((n, d), dtype=np.float32)
+        if n > 5:
+            x[5] = 0
+        a, b = x.copy(), x.copy()
+        gpu_faiss.normalize_L2(a)
+        oracle.normalize_l2(b)
+        assert np.array_equal(_bits(a), _bits(b))
+        if n > 5:
+            assert (a[5] == 0).all()
+
+
+# ---- edge cases ------------------------------------------------------------------------
+def test_edge_cases(gpu_faiss, oracle):
+    from knn_for_homology_amd._lib import Knn355Error
+    rng = np.random.default_rng(2)
+    xb = rng.standard_normal((50, 24), dtype=np.float32)
+    xq = rng.standard_normal((3, 24), dtype=np.float32)
+    fmax = np.finfo(np.float32).max
+    for metric, pad in ((0, -fmax), (1, fmax)):
+        idx = gpu_faiss.IndexFlat(24, metric)
+        # empty index: all slots unfilled
+        D, I = idx.search(xq, 4)
+        assert (I == -1).all() and (D == pad).all()
+        idx.add(xb)
+        # k > ntotal
+        D, I = idx.search(xq, 60)
+        _assert_same(D, I, *oracle.flat_search(xb, xq, 60, metric))
+        assert (I[:, 50:] == -1).all() and (D[:, 50:] == pad).all()
+        # no queries
+        D, I = idx.search(xq[:0], 4)
+        assert D.shape == (0, 4) and I.shape == (0, 4)
+        # several add calls == one add call (ids are insertion order)
+        idx2 = gpu_faiss.IndexFlat(24, metric)
+        idx2.add(xb[:7])
+        idx2.add(xb[7:8])
+        idx2.add(xb[8:])
+        assert idx2.ntotal == 50
+        _assert_same(*idx2.search(xq, 9), *oracle.flat_search(xb, xq, 9, metric))
+        assert np.array_equal(idx2.reconstruct_n(0, 50), xb)
+        idx2.reset()
+        assert idx2.ntotal == 0
+        # argument errors
+        with pytest.raises(Knn355Error):
+            idx.search(xq, 4096)
+        with pytest.raises(AssertionError):
+            idx.search(xq[:, :20].copy(), 3)
+        with pytest.raises(TypeError):
+            idx.add(xb.astype(np.float64))
+    with pytest.raises(Knn355Error):
+        gpu_faiss.IndexFlat(24, 7)
+
+
+def test_exact_duplicates_break_ties_by_lower_id(gpu_faiss, oracle):
+    rng = np.random.default_rng(4)
+    xb = rng.standard_normal((3000, 1024), dtype=np.float32)
+    xb[1500:1600] = xb[100:200]
+    xb[2900:2950] = xb[100:150]
+    q = xb[100:164].copy()
+    for metric, nch in ((0, 0), (1, 4), (1, 1)):
+        idx = gpu_faiss.IndexFlat(1024, metric)
+        idx.set_tuning(0, nch, 0)
+        idx.add(xb)
+        D, I = idx.search(q, 20)
+        _assert_same(D, I, *oracle.flat_search(xb, q, 20, metric))
+        assert (I[:50, 0] == np.arange(100, 150)).all()
+        assert (I[:50, 1] == np.arange(1500, 1550)).all() and (I[:50, 2] == np.arange(2900, 2950)).all()
+        if metric == 1:
+            assert (D[:50, :3] == 0).all()
+
+
+def test_result_independent_of_tiling(gpu_faiss):
+    """The same search under every query-tile / chunk split returns identical bits."""
+    rng = np.random.default_rng(8)
+    xb = rng.standard_normal((20000, 1024), dtype=np.float32)
+    xq = rng.standard_normal((96, 1024), dtype=np.float32)
+    idx = gpu_faiss.IndexFlat(1024, 0)
+    idx.add(xb)
+    ref = None
+    for qt, nch in ((0, 0), (32, 1), (32, 40), (64, 7), (128, 1), (128, 19)):
+        idx.set_tuning(qt, nch, 0)
+        D, I = idx.search(xq, 100)
+        if ref is None:
+            ref = (D, I)
+        else:
+            _assert_same(D, I, *ref)
+
+
+# ---- full-size configs: size-independent properties + sampled oracle rows ---------------
+def test_cath20_sized_all_vs_all(gpu_faiss, oracle):
+    """BASELINE config 2: 14433 x 1024 all-vs-all, L2, k=300 (+ self)."""
+    from knn_for_homology_amd.cath.search import search
+    rng = np.random.default_rng(20)
+    x = rng.standard_normal((14433, 1024), dtype=np.float32)
+    hits, scores = search(x, hits=300, metric=gpu_faiss.METRIC_L2)
+    assert hits.shape == (14433, 300)
+    assert (np.diff(scores, axis=1) >= 0).all(), "distances must be ascending"
+    assert (hits != np.arange(14433)[:, None]).all(), "self hit must be stripped"
+    srt = np.sort(hits, axis=1)
+    assert (srt[:, 1:] != srt[:, :-1]).all() and hits.min() >= 0 and hits.max() < 14433
+    sample = rng.choice(14433, 24, replace=False)
+    Do, Io = oracle.flat_search(x, x[sample], 301, 1)
+    _assert_same(scores[sample], hits[sample], Do[:, 1:], Io[:, 1:])
+    # cosine, reference default hits=10
+    hits, scores = search(x, hits=10)
+    xn = x.copy()
+    oracle.normalize_l2(xn)
+    Do, Io = oracle.flat_search(xn, xn[sample], 11, 0)
+    _assert_same(scores[sample], hits[sample], Do[:, 1:], Io[:, 1:])
+    assert (np.diff(scores, axis=1) <= 0).all()
+
+
+def test_large_shard_streaming(gpu_faiss, oracle):
+    """BASELINE config 4 shard shape: 1.25M x 1024 rows resident, inner product, k=100.
+    Properties: planted queries find themselves first; result identical under another
+    tiling; sampled queries equal the oracle bit for bit."""
+    import torch
+    from knn_for_homology_amd import _lib
+    L = _lib.lib()
+    nb, d, k = 1_250_000, 1024, 100
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(23)
+    idx = gpu_faiss.IndexFlat(d, 0)
+    _lib.check(L.knn_flat_reserve(idx._h, nb))
+    for i0 in range(0, nb, 250_000):
+        x = torch.randn((250_000, d), generator=g, device=dev)
+        _lib.check(L.knn_normalize_l2_dev(x.data_ptr(), 250_000, d, None))
+        _lib.check(L.knn_flat_add_dev(idx._h, x.data_ptr(), 250_000, None))
+        del x
+    assert idx.ntotal == nb
+    planted = np.array([0, 1, 777_777, nb - 1])
+    q = np.concatenate([idx.reconstruct(int(i))[None] for i in planted]
+                       + [np.random.default_rng(24).standard_normal((28, d), dtype=np.float32)])
+    gpu_faiss.normalize_L2(q)
+    D, I = idx.search(q, k)
+    assert (I[:4, 0] == planted).all() and np.allclose(D[:4, 0], 1.0, atol=1e-5)
+    assert (np.diff(D, axis=1) <= 0).all() and I.min() >= 0 and I.max() < nb
+    idx.set_tuning(128, 37, 0)
+    D2, I2 = idx.search(q, k)
+    _assert_same(D2, I2, D, I)
+    # oracle on a 200k-row window that contains two planted rows' neighbourhoods
+    w0, w1 = 700_000, 900_000
+    win = idx.reconstruct_n(w0, w1 - w0)
+    sub = gpu_faiss.IndexFlat(d, 0)
+    sub.add(win)
+    Ds, Is = sub.search(q[:8], k)
+    _assert_same(Ds, Is, *oracle.flat_search(win, q[:8], k, 0))

@@ -1,0 +1,121 @@
+"""CPU, world_size 2 over gloo: the sharded index's exchange (shard bounds, global ids in
+the packed keys, all-gather layout, merge order) with the local scan and the merge served
+by the oracle instead of the GPU.  The HIP-backed equivalent is tests/test_sharded_gpu.py."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _f2ord(v):
+    u = np.ascontiguousarray(v, np.float32).view(np.uint32).astype(np.uint64)
+    neg = (u & 0x80000000) != 0
+    return np.where(neg, (~u) & 0xFFFFFFFF, u | 0x80000000)
+
+
+def _ord2f(o):
+    o = o.astype(np.uint64)
+    u = np.where((o & 0x80000000) != 0, o & 0x7FFFFFFF, (~o) & 0xFFFFFFFF).astype(np.uint32)
+    return u.view(np.float32)
+
+
+class OracleShardBackend:
+    """Test double: same contract as HipShardBackend, arithmetic from the CPU oracle."""
+
+    def __init__(self, d, metric):
+        from oracle import knn_oracle as ko
+        self.ko, self.metric, self.d = ko, metric, d
+        self.rows = np.empty((0, d), np.float32)
+        self.index = None
+        self.device = torch.device("cpu")
+
+    def reserve(self, n):
+        pass
+
+    def add(self, x):
+        self.rows = np.concatenate([self.rows, x], 0)
+
+    @property
+    def ntotal(self):
+        return self.rows.shape[0]
+
+    def search_keys(self, q, k, id_base):
+        D, I = self.ko.oracle().flat_search(self.rows, q.numpy(), k, self.metric)
+        v = -D if self.metric == 0 else D
+        keys = (_f2ord(v + np.float32(0)) << np.uint64(32)) | (I.astype(np.uint64) + np.uint64(id_base))
+        keys[I < 0] = np.uint64(0xFFFFFFFFFFFFFFFF)
+        return torch.from_numpy(keys.view(np.int64))
+
+    def search(self, q, k):
+        D, I = self.ko.oracle().flat_search(self.rows, q.numpy(), k, self.metric)
+        return torch.from_numpy(D), torch.from_numpy(I)
+
+    def merge(self, gathered, nlists, nq, k):
+        g = gathered.numpy().view(np.uint64)                   # [world, nq, k]
+        allk = np.sort(np.transpose(g, (1, 0, 2)).reshape(nq, nlists * k), axis=1)[:, :k]
+        pad = allk == np.uint64(0xFFFFFFFFFFFFFFFF)
+        v = _ord2f(allk >> np.uint64(32))
+        D = np.where(pad, -np.finfo(np.float32).max if self.metric == 0 else np.finfo(np.float32).max,
+                     -v if self.metric == 0 else v).astype(np.float32)
+        I = np.where(pad, -1, (allk & np.uint64(0xFFFFFFFF)).astype(np.int64))
+        return torch.from_numpy(D), torch.from_numpy(I)
+
+
+def _worker(rank, world, port, metric, out_dir):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from knn_for_homology_amd.sharded import ShardedFlatIndex, shard_bounds
+    from test_sharded_cpu import OracleShardBackend
+    rng = np.random.default_rng(77)
+    xb = rng.standard_normal((1003, 64), dtype=np.float32)
+    xb[900:910] = xb[10:20]  # duplicates straddling the shard boundary: ties -> lower global id
+    xq = np.concatenate([rng.standard_normal((9, 64), dtype=np.float32), xb[10:14]])
+    lo, hi = shard_bounds(1003, world, rank)
+    idx = ShardedFlatIndex(64, metric, row_offset=lo, backend=OracleShardBackend(64, metric))
+    idx.add(xb[lo:hi])
+    D, I = idx.search(xq, 25)
+    np.savez(Path(out_dir) / f"r{rank}.npz", D=D, I=I)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_two_rank_gloo_equals_unsharded(tmp_path, metric):
+    from oracle import knn_oracle as ko
+    mp.spawn(_worker, args=(2, _free_port(), metric, str(tmp_path)), nprocs=2, join=True)
+    rng = np.random.default_rng(77)
+    xb = rng.standard_normal((1003, 64), dtype=np.float32)
+    xb[900:910] = xb[10:20]
+    xq = np.concatenate([rng.standard_normal((9, 64), dtype=np.float32), xb[10:14]])
+    Do, Io = ko.oracle().flat_search(xb, xq, 25, metric)
+    for r in range(2):
+        got = np.load(tmp_path / f"r{r}.npz")
+        assert np.array_equal(got["I"], Io), f"rank {r}: ids differ from the unsharded search"
+        assert np.array_equal(got["D"].view(np.uint32), Do.view(np.uint32))
+    assert (Io[9:, 0] == np.arange(10, 14)).all() and (Io[9:, 1] == np.arange(900, 904)).all()
+
+
+def test_shard_bounds_cover_everything():
+    from knn_for_homology_amd.sharded import shard_bounds
+    for n in (0, 1, 7, 8, 9, 1003, 10_000_000):
+        for w in (1, 2, 3, 4, 8):
+            spans = [shard_bounds(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
