@@ -176,6 +176,123 @@ __device__ __forceinline__ int next_pow2_dev(int n)
 }
 
 // ---------------------------------------------------------------------------
+// wave-wide selection over one candidate list (n <= 64*R packed keys in global
+// memory, pulled into registers).  Keeps the best keys -- exactly k when
+// kmax == k, otherwise any count in [k, kmax] -- and writes them packed to dst
+// (dst may alias lst).  No LDS, no barriers: four waves of a workgroup select
+// for four different queries at once.
+//   *thr_ord receives T with count(hi <= T) >= k, a valid admission threshold.
+// Method: MSB-first binary search on the 32-bit score word ("largest P with
+// count(hi < P) <= k-1"), each probe one v_cmp + s_bcnt1 per register, started
+// below the bits all keys share and stopped as soon as a probe leaves between k
+// and kmax survivors; ties that straddle the cut are broken on the id word.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int wave_sum(int x)
+{
+    // DPP butterfly inside each row of 16 lanes, then row broadcasts; lane 63 ends with the total
+    x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false);  // quad_perm:[1,0,3,2]
+    x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false);  // quad_perm:[2,3,0,1]
+    x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false); // row_half_mirror
+    x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false); // row_mirror
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false); // row_bcast:15 -> rows 1,3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false); // row_bcast:31 -> rows 2,3
+    return __builtin_amdgcn_readlane(x, 63);
+}
+
+template <int R>
+__device__ __attribute__((noinline)) int wave_select(const uint64_t *lst, int n, int k, int kmax, int lane, uint32_t *thr_ord, uint64_t *dst)
+{
+    uint32_t hi[R], lo[R];
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int idx = r * 64 + lane;
+        const bool valid = idx < n;
+        const uint64_t key = valid ? lst[idx] : KEY_PAD;
+        hi[r] = (uint32_t)(key >> 32);
+        lo[r] = (uint32_t)key;
+        if (valid) { mn = min(mn, hi[r]); mx = max(mx, hi[r]); }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        mn = min(mn, (uint32_t)__shfl_xor((int)mn, off, 64));
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
+    }
+    // per-lane partial counts (v_cmp + v_addc per register), one DPP reduction per probe
+    auto count_lt = [&](uint32_t X) {
+        int c = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) c += (hi[r] < X) ? 1 : 0;
+        return wave_sum(c);
+    };
+    uint32_t T = mx;
+    int cnt = n;
+    if (mn != mx) {
+        const int b0 = 31 - __clz((int)(mn ^ mx));
+        uint32_t P = (b0 == 31) ? 0u : (mx & ~((2u << b0) - 1u));
+        bool done = false;
+        for (int bit = b0; bit >= 0; --bit) {
+            const uint32_t Pt = P | (1u << bit);
+            const int c = count_lt(Pt);
+            if (c <= k - 1) {
+                P = Pt;
+            } else {
+                T = Pt - 1u;
+                cnt = c;
+                if (c <= kmax) { done = true; break; }
+            }
+        }
+        if (!done) { // P is the exact k-th smallest score word
+            T = P;
+            cnt = count_lt(P + 1u);
+        }
+    }
+    uint32_t Q = 0xFFFFFFFFu;
+    uint32_t Tlt = T; // keys with hi < Tlt are kept unconditionally, hi == T only with lo <= Q
+    if (cnt > kmax) {
+        // more keys tie at T than may be kept: lowest ids win
+        const int need = k - count_lt(T);
+        Q = 0u;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t Qt = Q | (1u << bit);
+            int c = 0;
+#pragma unroll
+            for (int r = 0; r < R; r++) c += (hi[r] == T && lo[r] < Qt) ? 1 : 0;
+            if (wave_sum(c) <= need - 1) Q = Qt;
+        }
+    }
+    // survivors: lane-major packing (order inside a list is irrelevant)
+    int mine = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) mine += (hi[r] < Tlt || (hi[r] == T && lo[r] <= Q)) ? 1 : 0;
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    int pos = incl - mine;
+    const int total = __shfl(incl, 63, 64);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        if (hi[r] < Tlt || (hi[r] == T && lo[r] <= Q)) dst[pos++] = ((uint64_t)hi[r] << 32) | lo[r];
+    }
+    *thr_ord = T;
+    return total;
+}
+
+__device__ __forceinline__ int wave_select_dispatch(int R, const uint64_t *lst, int n, int k, int kmax, int lane,
+                                                    uint32_t *thr_ord, uint64_t *dst)
+{
+    switch (R) {
+    case 8: return wave_select<8>(lst, n, k, kmax, lane, thr_ord, dst);
+    case 16: return wave_select<16>(lst, n, k, kmax, lane, thr_ord, dst);
+    case 32: return wave_select<32>(lst, n, k, kmax, lane, thr_ord, dst);
+    default: return wave_select<64>(lst, n, k, kmax, lane, thr_ord, dst);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // scan kernel
 // ---------------------------------------------------------------------------
 struct ScanParams {
@@ -193,6 +310,7 @@ struct ScanParams {
     uint32_t *gthr;    // [nqtiles*QT] shared running thresholds (order-mapped floats)
     uint64_t *partial; // [nq][nchunks][k]
     uint32_t id_base;
+    int dbg;           // timing experiments only: 2 = skip compaction, 4 = skip appends
 };
 
 template <bool GLDS>
@@ -365,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
                     } else {
                         v = -acc[a][b][r];
                     }
-                    if (v <= thr && row < c_hi && qok) {
+                    if (v <= thr && row < c_hi && qok && !(p.dbg & 4)) {
                         v = v + 0.0f;
                         int slot = atomicAdd(&s_cnt[ql], 1);
                         if (slot < p.cap)
@@ -380,33 +498,64 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 
         // ---- compaction of lists that could overflow on the next tile ----
         const bool last_tile = row0 + DT >= c_hi;
-        if (*s_need || last_tile) {
-            uint64_t *sb = (uint64_t *)smem;
-            for (int ql = 0; ql < QT; ql++) {
-                const int n = min(s_cnt[ql], p.cap);
-                if (!last_tile && n <= p.cap - DT) continue;
-                const int64_t q = q0 + ql;
-                uint64_t *lst = my_lists + (size_t)ql * p.cap;
-                const int P = next_pow2_dev(n > 0 ? n : 1);
-                for (int i = tid; i < P; i += 256) sb[i] = i < n ? lst[i] : KEY_PAD;
-                __syncthreads();
-                wg_bitonic_sort(sb, P, tid, 256);
-                const int keep = min(n, p.k);
-                if (!last_tile) {
-                    for (int i = tid; i < keep; i += 256) lst[i] = sb[i];
-                } else if (q < p.nq) {
-                    uint64_t *out = p.partial + ((size_t)q * p.nchunks + chunk) * p.k;
-                    for (int i = tid; i < p.k; i += 256) out[i] = i < keep ? sb[i] : KEY_PAD;
-                }
-                if (tid == 0) {
-                    s_cnt[ql] = keep;
-                    if (n >= p.k) {
-                        uint32_t o = (uint32_t)(sb[p.k - 1] >> 32);
-                        s_thr[ql] = ord2f(o);
-                        atomicMin(&p.gthr[qtile * QT + ql], o);
+        if ((*s_need || last_tile) && !(p.dbg & 2)) {
+            const int R = p.cap >> 6;
+            if (R <= 64) {
+                // one wave per query, registers only: four queries in flight per workgroup
+                for (int ql = wave; ql < QT; ql += 4) {
+                    const int n = __builtin_amdgcn_readfirstlane(min(s_cnt[ql], p.cap));
+                    uint64_t *lst = my_lists + (size_t)ql * p.cap;
+                    uint32_t T = 0;
+                    if (!last_tile) {
+                        if (n <= p.cap - DT) continue;
+                        const int cnt = wave_select_dispatch(R, lst, n, p.k, p.k + (p.k >> 2), lane, &T, lst);
+                        if (lane == 0) {
+                            s_cnt[ql] = cnt;
+                            s_thr[ql] = ord2f(T);
+                            atomicMin(&p.gthr[qtile * QT + ql], T);
+                        }
+                    } else {
+                        const int64_t q = q0 + ql;
+                        if (q >= p.nq) continue;
+                        uint64_t *out = p.partial + ((size_t)q * p.nchunks + chunk) * p.k;
+                        if (n > p.k) {
+                            wave_select_dispatch(R, lst, n, p.k, p.k, lane, &T, out); // exactly k, unsorted
+                            if (lane == 0) atomicMin(&p.gthr[qtile * QT + ql], T);
+                        } else {
+                            for (int i = lane; i < p.k; i += 64) out[i] = i < n ? lst[i] : KEY_PAD;
+                        }
                     }
                 }
                 __syncthreads();
+            } else {
+                // k close to KNN_MAX_K: lists too long for registers, whole-workgroup LDS sort
+                uint64_t *sb = (uint64_t *)smem;
+                for (int ql = 0; ql < QT; ql++) {
+                    const int n = min(s_cnt[ql], p.cap);
+                    if (!last_tile && n <= p.cap - DT) continue;
+                    const int64_t q = q0 + ql;
+                    uint64_t *lst = my_lists + (size_t)ql * p.cap;
+                    const int P = next_pow2_dev(n > 0 ? n : 1);
+                    for (int i = tid; i < P; i += 256) sb[i] = i < n ? lst[i] : KEY_PAD;
+                    __syncthreads();
+                    wg_bitonic_sort(sb, P, tid, 256);
+                    const int keep = min(n, p.k);
+                    if (!last_tile) {
+                        for (int i = tid; i < keep; i += 256) lst[i] = sb[i];
+                    } else if (q < p.nq) {
+                        uint64_t *out = p.partial + ((size_t)q * p.nchunks + chunk) * p.k;
+                        for (int i = tid; i < p.k; i += 256) out[i] = i < keep ? sb[i] : KEY_PAD;
+                    }
+                    if (tid == 0) {
+                        s_cnt[ql] = keep;
+                        if (n >= p.k) {
+                            uint32_t o = (uint32_t)(sb[p.k - 1] >> 32);
+                            s_thr[ql] = ord2f(o);
+                            atomicMin(&p.gthr[qtile * QT + ql], o);
+                        }
+                    }
+                    __syncthreads();
+                }
             }
             if (tid == 0) *s_need = 0;
             __syncthreads();
@@ -892,11 +1041,9 @@ static int search_keys_impl(knn_index_s *h, const float *q_dev, int64_t nq, int 
     }
     if (h->ws_lists.ensure((size_t)pl.grid * pl.qt * pl.cap * 8) || h->ws_gthr.ensure((size_t)pl.nqtiles * pl.qt * 4))
         return set_err(KNN_ERR_HIP, "search: out of device memory (candidate lists)");
-    uint64_t *partial = keys_out;
-    if (pl.nchunks > 1) {
-        if (h->ws_partial.ensure((size_t)nq * pl.nchunks * k * 8)) return set_err(KNN_ERR_HIP, "search: out of device memory");
-        partial = (uint64_t *)h->ws_partial.p;
-    }
+    // per-chunk survivor lists are unsorted: at least one merge round always follows
+    if (h->ws_partial.ensure((size_t)nq * pl.nchunks * k * 8)) return set_err(KNN_ERR_HIP, "search: out of device memory");
+    uint64_t *partial = (uint64_t *)h->ws_partial.p;
     HIP_TRY(hipMemsetAsync(h->ws_gthr.p, 0xFF, (size_t)pl.nqtiles * pl.qt * 4, s));
     ScanParams p;
     p.xb = h->xb; p.yn = h->yn; p.xq = q_dev; p.xn = xn;
@@ -904,6 +1051,7 @@ static int search_keys_impl(knn_index_s *h, const float *q_dev, int64_t nq, int 
     p.nqtiles = pl.nqtiles; p.nchunks = pl.nchunks; p.chunk_rows = pl.chunk_rows;
     p.lists = (uint64_t *)h->ws_lists.p; p.gthr = (uint32_t *)h->ws_gthr.p; p.partial = partial;
     p.id_base = id_base;
+    p.dbg = h->flags & 6;
     {
         const int slot = (int)(h->nlaunches % knn_index_s::RING);
         if (!h->ring0[slot]) {
@@ -926,13 +1074,15 @@ static int search_keys_impl(knn_index_s *h, const float *q_dev, int64_t nq, int 
     int L = pl.nchunks;
     const uint64_t *in = partial;
     bool flip = false;
-    while (L > 1) {
+    bool first = true;
+    while (L > 1 || first) {
+        first = false;
         int G = std::max(2, 8192 / next_pow2_host(k));
         int Lout = (L + G - 1) / G;
         uint64_t *out;
         if (Lout == 1) out = keys_out;
         else {
-            DevBuf &b = flip ? h->ws_partial : h->ws_partial2;
+            DevBuf &b = flip ? h->ws_partial : h->ws_partial2; // round 0 reads ws_partial, writes ws_partial2
             if (b.ensure((size_t)nq * Lout * k * 8)) return set_err(KNN_ERR_HIP, "search: out of device memory");
             out = (uint64_t *)b.p;
         }

@@ -71,7 +71,7 @@ if "stream" in which:
     _lib.check(L.knn_normalize_l2_dev(q.data_ptr(), 1024, 1024, None))
     for nq in (1, 8, 16, 32, 64, 128, 1024):
         run(idx, q[:nq].contiguous(), 100)
-    for nch in (256, 512, 2048):
+    for nch in (256, 512):
         print(f"  forced nchunks={nch}")
         run(idx, q[:32].contiguous(), 100, nch=nch)
     del idx
