@@ -199,8 +199,24 @@ __device__ __forceinline__ int wave_sum(int x)
     return __builtin_amdgcn_readlane(x, 63);
 }
 
-template <int R>
-__device__ __attribute__((noinline)) int wave_select(const uint64_t *lst, int n, int k, int kmax, int lane, uint32_t *thr_ord, uint64_t *dst)
+struct LoadContig {
+    const uint64_t *p;
+    __device__ __forceinline__ uint64_t operator()(int idx) const { return p[idx]; }
+};
+// element idx of the concatenation of lists l0.. of query q inside a [list][query][k] buffer
+struct LoadListMajor {
+    const uint64_t *base;
+    int64_t nq, q;
+    int k, l0;
+    __device__ __forceinline__ uint64_t operator()(int idx) const
+    {
+        const int l = idx / k, j = idx - l * k;
+        return base[((size_t)(l0 + l) * nq + q) * k + j];
+    }
+};
+
+template <int R, typename LD>
+__device__ __attribute__((noinline)) int wave_select(LD load, int n, int k, int kmax, int lane, uint32_t *thr_ord, uint64_t *dst)
 {
     uint32_t hi[R], lo[R];
     uint32_t mn = 0xFFFFFFFFu, mx = 0u;
@@ -208,7 +224,7 @@ __device__ __attribute__((noinline)) int wave_select(const uint64_t *lst, int n,
     for (int r = 0; r < R; r++) {
         const int idx = r * 64 + lane;
         const bool valid = idx < n;
-        const uint64_t key = valid ? lst[idx] : KEY_PAD;
+        const uint64_t key = valid ? load(idx) : KEY_PAD;
         hi[r] = (uint32_t)(key >> 32);
         lo[r] = (uint32_t)key;
         if (valid) { mn = min(mn, hi[r]); mx = max(mx, hi[r]); }
@@ -244,12 +260,12 @@ __device__ __attribute__((noinline)) int wave_select(const uint64_t *lst, int n,
         }
         if (!done) { // P is the exact k-th smallest score word
             T = P;
-            cnt = count_lt(P + 1u);
+            cnt = P == 0xFFFFFFFFu ? n : count_lt(P + 1u);
         }
     }
     uint32_t Q = 0xFFFFFFFFu;
-    uint32_t Tlt = T; // keys with hi < Tlt are kept unconditionally, hi == T only with lo <= Q
-    if (cnt > kmax) {
+    const uint32_t Tlt = T; // keys with hi < Tlt are kept unconditionally, hi == T only with lo <= Q
+    if (cnt > kmax && T != 0xFFFFFFFFu) { // (padding keys are interchangeable: the bounded store below trims them)
         // more keys tie at T than may be kept: lowest ids win
         const int need = k - count_lt(T);
         Q = 0u;
@@ -275,21 +291,23 @@ __device__ __attribute__((noinline)) int wave_select(const uint64_t *lst, int n,
     const int total = __shfl(incl, 63, 64);
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        if (hi[r] < Tlt || (hi[r] == T && lo[r] <= Q)) dst[pos++] = ((uint64_t)hi[r] << 32) | lo[r];
+        if (hi[r] < Tlt || (hi[r] == T && lo[r] <= Q)) {
+            if (pos < kmax) dst[pos] = ((uint64_t)hi[r] << 32) | lo[r];
+            pos++;
+        }
     }
     *thr_ord = T;
-    return total;
+    return min(total, kmax);
 }
 
-__device__ __forceinline__ int wave_select_dispatch(int R, const uint64_t *lst, int n, int k, int kmax, int lane,
+template <typename LD>
+__device__ __forceinline__ int wave_select_dispatch(int R, LD load, int n, int k, int kmax, int lane,
                                                     uint32_t *thr_ord, uint64_t *dst)
 {
-    switch (R) {
-    case 8: return wave_select<8>(lst, n, k, kmax, lane, thr_ord, dst);
-    case 16: return wave_select<16>(lst, n, k, kmax, lane, thr_ord, dst);
-    case 32: return wave_select<32>(lst, n, k, kmax, lane, thr_ord, dst);
-    default: return wave_select<64>(lst, n, k, kmax, lane, thr_ord, dst);
-    }
+    if (R <= 8) return wave_select<8, LD>(load, n, k, kmax, lane, thr_ord, dst);
+    if (R <= 16) return wave_select<16, LD>(load, n, k, kmax, lane, thr_ord, dst);
+    if (R <= 32) return wave_select<32, LD>(load, n, k, kmax, lane, thr_ord, dst);
+    return wave_select<64, LD>(load, n, k, kmax, lane, thr_ord, dst);
 }
 
 // ---------------------------------------------------------------------------
@@ -508,7 +526,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
                     uint32_t T = 0;
                     if (!last_tile) {
                         if (n <= p.cap - DT) continue;
-                        const int cnt = wave_select_dispatch(R, lst, n, p.k, p.k + (p.k >> 2), lane, &T, lst);
+                        const int cnt = wave_select_dispatch(R, LoadContig{lst}, n, p.k, p.k + (p.k >> 2), lane, &T, lst);
                         if (lane == 0) {
                             s_cnt[ql] = cnt;
                             s_thr[ql] = ord2f(T);
@@ -519,7 +537,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
                         if (q >= p.nq) continue;
                         uint64_t *out = p.partial + ((size_t)q * p.nchunks + chunk) * p.k;
                         if (n > p.k) {
-                            wave_select_dispatch(R, lst, n, p.k, p.k, lane, &T, out); // exactly k, unsorted
+                            wave_select_dispatch(R, LoadContig{lst}, n, p.k, p.k, lane, &T, out); // exactly k, unsorted
                             if (lane == 0) atomicMin(&p.gthr[qtile * QT + ql], T);
                         } else {
                             for (int i = lane; i < p.k; i += 64) out[i] = i < n ? lst[i] : KEY_PAD;
@@ -564,35 +582,81 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 }
 
 // ---------------------------------------------------------------------------
-// merge: in [nq][L][k] (or [L][nq][k] when list_major) -> out [nq][Lout][k]
-// each workgroup sorts the union of up to G lists of one query
+// merge: one WAVE per (query, group of <= G lists).  in is [nq][L][k] or, for an
+// all-gather buffer, [L][nq][k]; lists are unsorted and padded with KEY_PAD.
+// The wave pulls the group's <= 4096 keys into registers, keeps the best k
+// (wave_select, exact) and either writes them on as an unsorted list
+// (out_keys [nq][Lout][k], more rounds follow) or -- last round, Lout == 1 --
+// sorts them in LDS and emits the final D / I (or sorted keys).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void merge_keys_kernel(const uint64_t *__restrict__ in, int L, int k,
-                                                         int64_t nq, int list_major, int G, int Lout,
-                                                         uint64_t *__restrict__ out)
+template <bool LISTMAJOR>
+__global__ __launch_bounds__(256) void merge_select_kernel(const uint64_t *__restrict__ in, int L, int k, int64_t nq,
+                                                           int G, int Lout, uint64_t *__restrict__ out_keys,
+                                                           int final_round, int metric, float *__restrict__ D,
+                                                           int64_t *__restrict__ I)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint64_t *sb = (uint64_t *)smem;
-    const int tid = threadIdx.x;
-    const int64_t q = blockIdx.x / Lout;
-    const int g = blockIdx.x % Lout;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int P = 64;
+    while (P < k) P <<= 1;
+    uint64_t *sb = (uint64_t *)smem + (size_t)wave * P;
+    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t nitems = nq * Lout;
+    const bool active = item < nitems;
+    const int64_t q = active ? item / Lout : 0;
+    const int g = active ? (int)(item % Lout) : 0;
     const int l0 = g * G, l1 = min(L, l0 + G);
     const int n = (l1 - l0) * k;
-    int P = 64;
-    while (P < n) P <<= 1;
-    for (int i = tid; i < P; i += 256) {
-        uint64_t v = KEY_PAD;
-        if (i < n) {
-            int l = l0 + i / k, j = i % k;
-            size_t idx = list_major ? ((size_t)l * nq + q) * k + j : ((size_t)q * L + l) * k + j;
-            v = in[idx];
+    uint64_t *dst = final_round ? sb : out_keys + ((size_t)q * Lout + g) * k;
+    if (active) {
+        int have = n;
+        if (n > k) {
+            uint32_t T;
+            const int R = (n + 63) >> 6;
+            if constexpr (LISTMAJOR)
+                have = wave_select_dispatch(R, LoadListMajor{in, nq, q, k, l0}, n, k, k, lane, &T, dst);
+            else
+                have = wave_select_dispatch(R, LoadContig{in + ((size_t)q * L + l0) * k}, n, k, k, lane, &T, dst);
+        } else {
+            for (int i = lane; i < n; i += 64) {
+                if constexpr (LISTMAJOR) dst[i] = LoadListMajor{in, nq, q, k, l0}(i);
+                else dst[i] = in[((size_t)q * L + l0) * k + i];
+            }
         }
-        sb[i] = v;
+        const int fill_to = final_round ? P : k;
+        for (int i = have + lane; i < fill_to; i += 64) dst[i] = KEY_PAD;
     }
+    if (!final_round) return;
     __syncthreads();
-    wg_bitonic_sort(sb, P, tid, 256);
-    uint64_t *o = out + ((size_t)q * Lout + g) * k;
-    for (int i = tid; i < k; i += 256) o[i] = i < n ? sb[i] : KEY_PAD;
+    // every wave sorts its own P keys; identical control flow in all four waves
+    for (int k2 = 2; k2 <= P; k2 <<= 1) {
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int i = lane; i < (P >> 1); i += 64) {
+                const int a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                const int b = a + j;
+                const bool up = (a & k2) == 0;
+                const uint64_t x = sb[a], y = sb[b];
+                if ((x > y) == up) { sb[a] = y; sb[b] = x; }
+            }
+            __syncthreads();
+        }
+    }
+    if (!active) return;
+    for (int i = lane; i < k; i += 64) {
+        const uint64_t key = sb[i];
+        const size_t o = (size_t)q * k + i;
+        if (out_keys) out_keys[o] = key;
+        if (D) {
+            if (key == KEY_PAD) {
+                D[o] = metric == KNN_METRIC_INNER_PRODUCT ? -FLT_MAX : FLT_MAX;
+                I[o] = -1;
+            } else {
+                const float v = ord2f((uint32_t)(key >> 32));
+                D[o] = metric == KNN_METRIC_INNER_PRODUCT ? -v : v;
+                I[o] = (int64_t)(uint32_t)key;
+            }
+        }
+    }
 }
 
 __global__ void finalize_kernel(const uint64_t *__restrict__ keys, int64_t total, int metric,
@@ -969,6 +1033,55 @@ extern "C" int knn_flat_reconstruct(knn_handle h, int64_t i0, int64_t n, float *
 }
 
 // ---- search ---------------------------------------------------------------
+static int next_pow2_host(int n)
+{
+    int p = 64;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+// Runs merge rounds over `in` (L lists of k keys per query) until one list is left;
+// the last round sorts and writes keys_out (may be null) and/or D/I (may be null).
+// tmp0/tmp1: ping-pong buffers for intermediate rounds.
+static int run_merge(const uint64_t *in, int L, int k, int64_t nq, bool list_major, DevBuf &tmp0, DevBuf &tmp1,
+                     uint64_t *keys_out, int metric, float *D, int64_t *I, hipStream_t s)
+{
+    const int G = std::max(2, 4096 / k);
+    const size_t lds_final = (size_t)4 * next_pow2_host(k) * 8;
+    bool lm = list_major;
+    int round = 0;
+    for (;;) {
+        const int Lout = (L + G - 1) / G;
+        const bool final_round = Lout == 1;
+        uint64_t *out = nullptr;
+        if (!final_round) {
+            DevBuf &b = (round & 1) ? tmp1 : tmp0;
+            if (b.ensure((size_t)nq * Lout * k * 8)) return set_err(KNN_ERR_HIP, "merge: out of device memory");
+            out = (uint64_t *)b.p;
+        } else {
+            out = keys_out;
+        }
+        const int64_t items = nq * Lout;
+        const unsigned grid = (unsigned)((items + 3) / 4);
+        const size_t lds = final_round ? lds_final : 0;
+        if (lm) {
+            if (lds > 65536) HIP_TRY(hipFuncSetAttribute((const void *)merge_select_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(merge_select_kernel<true>, dim3(grid), dim3(256), lds, s, in, L, k, nq, G, Lout, out,
+                               final_round ? 1 : 0, metric, D, I);
+        } else {
+            if (lds > 65536) HIP_TRY(hipFuncSetAttribute((const void *)merge_select_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(merge_select_kernel<false>, dim3(grid), dim3(256), lds, s, in, L, k, nq, G, Lout, out,
+                               final_round ? 1 : 0, metric, D, I);
+        }
+        HIP_TRY(hipGetLastError());
+        if (final_round) return 0;
+        in = out;
+        L = Lout;
+        lm = false;
+        round++;
+    }
+}
+
 struct ScanPlan {
     int qt, dt, nqtiles, nchunks, cap, grid;
     int64_t chunk_rows;
@@ -976,12 +1089,6 @@ struct ScanPlan {
     const char *name;
 };
 
-static int next_pow2_host(int n)
-{
-    int p = 64;
-    while (p < n) p <<= 1;
-    return p;
-}
 
 template <int WM, int WN, int TM, int TN>
 static int launch_scan_cfg(const knn_index_s *h, const ScanParams &p, const ScanPlan &plan, hipStream_t s)
@@ -1028,7 +1135,7 @@ static void make_plan(const knn_index_s *h, int64_t nq, int k, ScanPlan &pl)
 
 // queries [nq][dp] already on device (padded); writes sorted keys [nq][k]
 static int search_keys_impl(knn_index_s *h, const float *q_dev, int64_t nq, int k, uint32_t id_base,
-                            uint64_t *keys_out, hipStream_t s)
+                            uint64_t *keys_out, float *D_out, int64_t *I_out, hipStream_t s)
 {
     ScanPlan pl;
     make_plan(h, nq, k, pl);
@@ -1070,32 +1177,8 @@ static int search_keys_impl(knn_index_s *h, const float *q_dev, int64_t nq, int 
     if (rc) return rc;
     HIP_TRY(hipEventRecord(h->ev1, s));
     h->last_kernel = pl.name; h->last_qt = pl.qt; h->last_dt = pl.dt; h->last_chunks = pl.nchunks; h->last_grid = pl.grid;
-    // merge rounds
-    int L = pl.nchunks;
-    const uint64_t *in = partial;
-    bool flip = false;
-    bool first = true;
-    while (L > 1 || first) {
-        first = false;
-        int G = std::max(2, 8192 / next_pow2_host(k));
-        int Lout = (L + G - 1) / G;
-        uint64_t *out;
-        if (Lout == 1) out = keys_out;
-        else {
-            DevBuf &b = flip ? h->ws_partial : h->ws_partial2; // round 0 reads ws_partial, writes ws_partial2
-            if (b.ensure((size_t)nq * Lout * k * 8)) return set_err(KNN_ERR_HIP, "search: out of device memory");
-            out = (uint64_t *)b.p;
-        }
-        int n = std::min(L, G) * k;
-        size_t lds = (size_t)next_pow2_host(n) * 8;
-        HIP_TRY(hipFuncSetAttribute((const void *)merge_keys_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(merge_keys_kernel, dim3((unsigned)(nq * Lout)), dim3(256), lds, s, in, L, k, nq, 0, G, Lout, out);
-        HIP_TRY(hipGetLastError());
-        in = out;
-        L = Lout;
-        flip = !flip;
-    }
-    return 0;
+    // merge rounds: per-chunk survivor lists -> sorted top-k (+ D/I)
+    return run_merge(partial, pl.nchunks, k, nq, false, h->ws_partial2, h->ws_tmp, keys_out, h->metric, D_out, I_out, s);
 }
 
 static int check_search_args(knn_index_s *h, const void *q, int64_t nq, int64_t k, const void *D, const void *I)
@@ -1138,19 +1221,7 @@ static int search_dev_impl(knn_index_s *h, const float *q_dev, int64_t nq, int k
         HIP_TRY(hipGetLastError());
         qp = (const float *)h->ws_q.p;
     }
-    uint64_t *keys = keys_dev;
-    if (!keys) {
-        if (h->ws_keys.ensure((size_t)total * 8)) return set_err(KNN_ERR_HIP, "search: out of device memory");
-        keys = (uint64_t *)h->ws_keys.p;
-    }
-    int rc = search_keys_impl(h, qp, nq, k, id_base, keys, s);
-    if (rc) return rc;
-    if (!keys_dev) {
-        hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
-                           (const uint64_t *)keys, total, h->metric, D_dev, I_dev);
-        HIP_TRY(hipGetLastError());
-    }
-    return 0;
+    return search_keys_impl(h, qp, nq, k, id_base, keys_dev, D_dev, I_dev, s);
 }
 
 extern "C" int knn_flat_search_dev(knn_handle h, const float *q_dev, int64_t nq, int64_t k, float *D_dev,
@@ -1188,38 +1259,15 @@ extern "C" int knn_merge_keys_dev(int32_t device, int32_t metric, const uint64_t
 {
     if (nlists < 1 || nq < 0 || k < 1 || k > KNN_MAX_K) return set_err(KNN_ERR_INVALID, "merge_keys: bad shape");
     if (nq == 0) return 0;
+    if (!keys_dev || !D_dev || !I_dev) return set_err(KNN_ERR_INVALID, "merge_keys: null pointer");
     int rc = ensure_device(device);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const int64_t total = nq * k;
-    const uint64_t *in = keys_dev;
-    uint64_t *bufs[2] = {nullptr, nullptr};
-    int L = nlists;
-    int list_major = 1;
-    int cur = 0;
-    auto cleanup = [&]() { for (auto b : bufs) if (b) (void)hipFree(b); };
-    while (L > 1) {
-        int G = std::max(2, 8192 / next_pow2_host((int)k));
-        int Lout = (L + G - 1) / G;
-        if (!bufs[cur]) {
-            if (hipMalloc((void **)&bufs[cur], (size_t)nq * Lout * k * 8) != hipSuccess) { cleanup(); return set_err(KNN_ERR_HIP, "merge_keys: out of device memory"); }
-        }
-        int n = std::min(L, G) * (int)k;
-        size_t lds = (size_t)next_pow2_host(n) * 8;
-        (void)hipFuncSetAttribute((const void *)merge_keys_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(merge_keys_kernel, dim3((unsigned)(nq * Lout)), dim3(256), lds, s, in, L, (int)k, nq,
-                           list_major, G, Lout, bufs[cur]);
-        if (hipGetLastError() != hipSuccess) { cleanup(); return set_err(KNN_ERR_HIP, "merge_keys: launch failed"); }
-        in = bufs[cur];
-        L = Lout;
-        list_major = 0;
-        cur ^= 1;
-    }
-    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, total, metric, D_dev, I_dev);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    cleanup();
-    if (e != hipSuccess) return set_err(KNN_ERR_HIP, std::string("merge_keys: ") + hipGetErrorString(e));
+    // intermediate rounds only exist for nlists > 4096/k (more than 40 shards at k=100)
+    static thread_local DevBuf t0, t1;
+    rc = run_merge(keys_dev, nlists, (int)k, nq, true, t0, t1, nullptr, metric, D_dev, I_dev, s);
+    if (rc) return rc;
+    if (!stream) HIP_TRY(hipStreamSynchronize(s));
     return 0;
 }
 
