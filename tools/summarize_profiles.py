@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 output of tools/collect_profiles.sh (gpurun_out/) into the
+committed summaries under profiles/: kernel stats CSV, per-kernel HBM traffic from the
+PMC passes (FETCH_SIZE doubled for wide streaming reads on gfx950 as
+MI355X_MICROARCH.md section HBM prescribes; units are KiB), and pmc_traffic.json which
+bench.py reads for roofline.traffic.  usage: summarize_profiles.py <round-tag>"""
+import collections
+import csv
+import json
+import shutil
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+out = ROOT / "profiles"
+out.mkdir(exist_ok=True)
+go = ROOT / "gpurun_out"
+
+stats = go / f"prof_{tag}" / f"{tag}_kernel_stats.csv"
+shutil.copyfile(stats, out / f"{tag}_bench_kernel_stats.csv")
+bench_json = go / f"bench_prof_{tag}.json"
+if bench_json.exists():
+    shutil.copyfile(bench_json, out / f"{tag}_bench_under_rocprof.json")
+
+
+def short(name):
+    if "flat_scan_kernel<4, 1, 2, 1" in name:
+        return "flat_scan_q32_d256"
+    if "flat_scan_kernel<2, 2, 2, 1" in name:
+        return "flat_scan_q64_d128"
+    if "flat_scan_kernel<2, 2, 2, 2" in name:
+        return "flat_scan_q128_d128"
+    return name.split("(")[0].replace("void ", "")[:60]
+
+
+def per_kernel(path, counter):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return agg
+
+
+fetch = per_kernel(go / f"pmc_fetch_{tag}" / "f_counter_collection.csv", "FETCH_SIZE")
+write = per_kernel(go / f"pmc_write_{tag}" / "w_counter_collection.csv", "WRITE_SIZE")
+traffic = {}
+rows = []
+for kname in sorted(set(fetch) | set(write)):
+    f = fetch.get(kname, [])
+    w = write.get(kname, [])
+    # per launch: the bench's timed launches are the largest ones of that kernel
+    fmax = max(f) if f else 0.0
+    wmax = max(w) if w else 0.0
+    hbm = (2.0 * fmax + wmax) * 1024.0
+    rows.append((kname, len(f), fmax, wmax, hbm))
+    if kname.startswith("flat_scan") or kname.startswith("merge_select"):
+        traffic[kname] = {"hbm_bytes_per_launch": hbm, "fetch_size_kib_raw": fmax, "write_size_kib": wmax,
+                          "note": "FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, largest launch"}
+with open(out / f"{tag}_pmc_hbm_traffic.csv", "w") as fh:
+    fh.write("kernel,launches,FETCH_SIZE_KiB_raw_max,WRITE_SIZE_KiB_max,hbm_bytes_corrected\n")
+    for r in rows:
+        fh.write(",".join(str(x) for x in r) + "\n")
+(out / "pmc_traffic.json").write_text(json.dumps(traffic, indent=1))
+print(open(out / f"{tag}_bench_kernel_stats.csv").read()[:1500])
+print(json.dumps(traffic, indent=1))
