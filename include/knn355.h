@@ -103,6 +103,36 @@ int knn_reset(knn_handle h);
 int knn_flat_reconstruct(knn_handle h, int64_t i0, int64_t n, float *out_host);
 void knn_free(knn_handle h);
 
+/* ---- faiss.IndexHNSWFlat(d, M, metric) ------------------------------------
+ * pfam/proteins_search.py:27-31 (M = 42, inner product, hnsw.efSearch = 256),
+ * .train (no-op) / .add :35-37, .search(x, 1000) :49.  The graph is built and walked
+ * on the host; all distances come from the GPU in lock-step batches.  Results use
+ * the flat index's layout; slots the walk could not fill hold id -1. */
+typedef struct knn_hnsw_s *knn_hnsw_handle;
+int knn_hnsw_create(int32_t d, int32_t M, int32_t metric, knn_hnsw_handle *out);
+/* index.hnsw.efSearch / index.hnsw.efConstruction (values <= 0 leave the setting alone) */
+int knn_hnsw_set_ef(knn_hnsw_handle h, int32_t efSearch, int32_t efConstruction);
+int knn_hnsw_get_params(knn_hnsw_handle h, int32_t *M, int32_t *efSearch, int32_t *efConstruction,
+                        int32_t *max_level, int64_t *entry_point);
+int knn_hnsw_add(knn_hnsw_handle h, const float *x_host, int64_t n);
+int knn_hnsw_search(knn_hnsw_handle h, const float *q_host, int64_t nq, int64_t k, float *D_host,
+                    int64_t *I_host);
+int64_t knn_hnsw_ntotal(knn_hnsw_handle h);
+/* the flat storage underneath (index.storage); owned by the HNSW handle */
+knn_handle knn_hnsw_storage(knn_hnsw_handle h);
+void knn_hnsw_free(knn_hnsw_handle h);
+/* graph tables for write_index / read_index: levels[n], offsets[n+1], nbrs[nslots]
+ * (-1 = empty), cum_nb[nlevels_tab] (slots below each level), assign_probas */
+int knn_hnsw_graph_sizes(knn_hnsw_handle h, int64_t *ntotal, int64_t *nslots, int32_t *nlevels_tab);
+int knn_hnsw_graph_export(knn_hnsw_handle h, int32_t *levels, int64_t *offsets, int32_t *nbrs,
+                          int32_t *cum_nb, double *assign_probas);
+int knn_hnsw_graph_import(knn_hnsw_handle h, int64_t ntotal, const int32_t *levels, const int32_t *nbrs,
+                          int64_t nslots, int32_t max_level, int64_t entry_point);
+/* work counters since the last reset: (query,row) pairs evaluated, lock-step rounds,
+ * pruned neighbour lists, seconds spent on GPU round trips and on the host walk */
+int knn_hnsw_stats(knn_hnsw_handle h, int64_t *pairs, int64_t *rounds, int64_t *shrinks, double *gpu_s,
+                   double *host_s, int32_t reset);
+
 /* ---- distances for explicit candidate lists (HNSW walk offload) --------
  * For query i (row of q_dev [nq,d]) and candidates cand[off[i] .. off[i+1]),
  * out[p] = <q,y> (IP) or max(0, |q|^2+|y|^2-2<q,y>) (L2), same arithmetic as

@@ -51,6 +51,18 @@ def _declare(L):
         "knn_last_scan_info": (c_int32, [H, c_char_p, c_int32, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
         "knn_last_scan_ms": (c_float, [H]),
         "knn_set_tuning": (c_int32, [H, c_int32, c_int32, c_int32]),
+        "knn_hnsw_create": (c_int32, [c_int32, c_int32, c_int32, POINTER(H)]),
+        "knn_hnsw_set_ef": (c_int32, [H, c_int32, c_int32]),
+        "knn_hnsw_get_params": (c_int32, [H, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int64)]),
+        "knn_hnsw_add": (c_int32, [H, c_void_p, c_int64]),
+        "knn_hnsw_search": (c_int32, [H, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+        "knn_hnsw_ntotal": (c_int64, [H]),
+        "knn_hnsw_storage": (H, [H]),
+        "knn_hnsw_free": (None, [H]),
+        "knn_hnsw_graph_sizes": (c_int32, [H, POINTER(c_int64), POINTER(c_int64), POINTER(c_int32)]),
+        "knn_hnsw_graph_export": (c_int32, [H, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+        "knn_hnsw_graph_import": (c_int32, [H, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_int64]),
+        "knn_hnsw_stats": (c_int32, [H, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), POINTER(ctypes.c_double), POINTER(ctypes.c_double), c_int32]),
         "knn_scan_times": (c_int32, [H, c_void_p, c_int32]),
         "knn_flat_reserve": (c_int32, [H, c_int64]),
     }

@@ -1431,3 +1431,5 @@ extern "C" int knn_gather_distances(knn_handle h, const float *q_host, int64_t n
     HIP_TRY(hipStreamSynchronize(s));
     return 0;
 }
+
+#include "hnsw.inc"

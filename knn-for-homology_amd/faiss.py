@@ -140,3 +140,226 @@ class IndexFlatIP(IndexFlat):
 class IndexFlatL2(IndexFlat):
     def __init__(self, d):
         super().__init__(d, METRIC_L2)
+
+
+class _HNSW:
+    """``index.hnsw``: the graph parameters the reference touches (``efSearch``,
+    pfam/proteins_search.py:31) plus read-only structure."""
+
+    def __init__(self, owner):
+        object.__setattr__(self, "_owner", owner)
+
+    def _params(self):
+        M, efs, efc, ml = (ctypes.c_int32() for _ in range(4))
+        ep = ctypes.c_int64()
+        _lib.check(_lib.lib().knn_hnsw_get_params(self._owner._h, ctypes.byref(M), ctypes.byref(efs), ctypes.byref(efc),
+                                                  ctypes.byref(ml), ctypes.byref(ep)))
+        return {"M": M.value, "efSearch": efs.value, "efConstruction": efc.value, "max_level": ml.value,
+                "entry_point": ep.value}
+
+    def __getattr__(self, name):
+        p = self._params()
+        if name in p:
+            return p[name]
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        if name == "efSearch":
+            _lib.check(_lib.lib().knn_hnsw_set_ef(self._owner._h, int(value), -1))
+        elif name == "efConstruction":
+            _lib.check(_lib.lib().knn_hnsw_set_ef(self._owner._h, -1, int(value)))
+        else:
+            raise AttributeError(f"hnsw.{name} is read-only")
+
+
+class IndexHNSWFlat(Index):
+    """faiss.IndexHNSWFlat(d, M, metric): HNSW graph over flat float32 storage.  The graph
+    is built and walked on the host (libknn355's C++), every distance is computed on the
+    GPU in lock-step batches (pfam/proteins_search.py:27-31)."""
+
+    def __init__(self, d, M=32, metric=METRIC_L2):
+        self._h = ctypes.c_void_p()
+        self._d = int(d)
+        self._metric = int(metric)
+        _lib.check(_lib.lib().knn_hnsw_create(self._d, int(M), self._metric, ctypes.byref(self._h)))
+        self.hnsw = _HNSW(self)
+
+    @property
+    def d(self):
+        return self._d
+
+    @property
+    def metric_type(self):
+        return self._metric
+
+    @property
+    def ntotal(self):
+        return int(_lib.lib().knn_hnsw_ntotal(self._h)) if self._h else 0
+
+    def add(self, x):
+        _check_matrix(x, self._d)
+        _lib.check(_lib.lib().knn_hnsw_add(self._h, x.ctypes.data, x.shape[0]))
+
+    def search(self, x, k):
+        _check_matrix(x, self._d)
+        k = int(k)
+        if k < 1:
+            raise AssertionError("k must be positive")
+        D = np.empty((x.shape[0], k), np.float32)
+        I = np.empty((x.shape[0], k), np.int64)
+        _lib.check(_lib.lib().knn_hnsw_search(self._h, x.ctypes.data, x.shape[0], k, D.ctypes.data, I.ctypes.data))
+        return D, I
+
+    def reconstruct_n(self, i0=0, n=None):
+        n = self.ntotal - i0 if n is None else n
+        out = np.empty((n, self._d), np.float32)
+        _lib.check(_lib.lib().knn_flat_reconstruct(_lib.lib().knn_hnsw_storage(self._h), i0, n, out.ctypes.data))
+        return out
+
+    def graph(self):
+        """(levels int32 [n], offsets int64 [n+1], neighbors int32 [nslots] with -1 = empty,
+        cum_nneighbor_per_level int32, assign_probas float64)"""
+        L = _lib.lib()
+        n, ns = ctypes.c_int64(), ctypes.c_int64()
+        nl = ctypes.c_int32()
+        _lib.check(L.knn_hnsw_graph_sizes(self._h, ctypes.byref(n), ctypes.byref(ns), ctypes.byref(nl)))
+        levels = np.empty(n.value, np.int32)
+        offsets = np.empty(n.value + 1, np.int64)
+        nbrs = np.empty(ns.value, np.int32)
+        cum = np.empty(nl.value, np.int32)
+        probas = np.empty(max(nl.value - 1, 0), np.float64)
+        _lib.check(L.knn_hnsw_graph_export(self._h, levels.ctypes.data, offsets.ctypes.data, nbrs.ctypes.data,
+                                           cum.ctypes.data, probas.ctypes.data))
+        return levels, offsets, nbrs, cum, probas
+
+    def stats(self, reset=False):
+        pairs, rounds, shrinks = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        g, h = ctypes.c_double(), ctypes.c_double()
+        _lib.check(_lib.lib().knn_hnsw_stats(self._h, ctypes.byref(pairs), ctypes.byref(rounds), ctypes.byref(shrinks),
+                                             ctypes.byref(g), ctypes.byref(h), 1 if reset else 0))
+        return {"pairs": pairs.value, "rounds": rounds.value, "shrinks": shrinks.value, "gpu_s": g.value, "host_s": h.value}
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _lib.lib().knn_hnsw_free(h)
+            except Exception:
+                pass
+            self._h = None
+
+
+# ---------------------------------------------------------------------------
+# write_index / read_index -- FAISS 1.7.2 binary layout (impl/index_write.cpp,
+# impl/index_read.cpp; restated from the published format, the FAISS sources are not
+# part of the reference tree):
+#   fourcc, header {int d; int64 ntotal; int64 dummy=1<<20 (x2); bool is_trained;
+#   int metric_type}, then per type
+#     "IxFI"/"IxF2"  IndexFlat : vector<float> xb (size_t count + data)
+#     "IHNf"         IndexHNSWFlat : HNSW {vector<double> assign_probas; vector<int>
+#                    cum_nneighbor_per_level; vector<int> levels (top level + 1);
+#                    vector<size_t> offsets; vector<int> neighbors (-1 = empty);
+#                    int entry_point, max_level, efConstruction, efSearch, upper_beam}
+#                    followed by the storage index ("IxFI"/"IxF2")
+#     "IxHe"         IndexLSH (see lsh.py)
+# Reference call sites: pfam/proteins_search.py:39-40, seqvec_search/create_index.py:47,
+# pfam/search.py:32,34, seqvec_search/main.py:132.
+# ---------------------------------------------------------------------------
+import struct as _struct
+
+
+def _w_vec(f, arr, dtype):
+    a = np.ascontiguousarray(arr, dtype=dtype)
+    f.write(_struct.pack("<Q", a.size))
+    f.write(a.tobytes())
+
+
+def _r_vec(f, dtype):
+    (n,) = _struct.unpack("<Q", f.read(8))
+    a = np.frombuffer(f.read(n * np.dtype(dtype).itemsize), dtype=dtype)
+    if a.size != n:
+        raise RuntimeError("read_index: truncated file")
+    return a
+
+
+def _w_header(f, fourcc, d, ntotal, metric):
+    f.write(fourcc)
+    f.write(_struct.pack("<iqqq?i", d, ntotal, 1 << 20, 1 << 20, True, metric))
+
+
+def _r_header(f):
+    d, ntotal, _, _, trained, metric = _struct.unpack("<iqqq?i", f.read(4 + 8 * 3 + 1 + 4))
+    if metric > 1:
+        f.read(4)  # metric_arg
+    return d, ntotal, metric
+
+
+def _write_flat(f, d, metric, rows):
+    _w_header(f, b"IxFI" if metric == METRIC_INNER_PRODUCT else b"IxF2", d, rows.shape[0], metric)
+    _w_vec(f, rows.reshape(-1), np.float32)
+
+
+def write_index(index, fname):
+    """faiss.write_index(index, str(path))"""
+    with open(str(fname), "wb") as f:
+        if isinstance(index, IndexHNSWFlat):
+            levels, offsets, nbrs, cum, probas = index.graph()
+            p = index.hnsw._params()
+            _w_header(f, b"IHNf", index.d, index.ntotal, index.metric_type)
+            _w_vec(f, probas, np.float64)
+            _w_vec(f, cum, np.int32)
+            _w_vec(f, levels + 1, np.int32)
+            _w_vec(f, offsets, np.uint64)
+            _w_vec(f, nbrs, np.int32)
+            f.write(_struct.pack("<iiiii", int(p["entry_point"]), int(p["max_level"]), int(p["efConstruction"]),
+                                 int(p["efSearch"]), 1))
+            _write_flat(f, index.d, index.metric_type, index.reconstruct_n(0, index.ntotal))
+        elif isinstance(index, IndexFlat):
+            _write_flat(f, index.d, index.metric_type, index.reconstruct_n(0, index.ntotal))
+        elif hasattr(index, "_write"):
+            index._write(f)
+        else:
+            raise RuntimeError(f"write_index: unsupported index type {type(index).__name__}")
+
+
+def read_index(fname):
+    """faiss.read_index(str(path)) -> index (rows go back to the GPU)"""
+    with open(str(fname), "rb") as f:
+        return _read_index(f)
+
+
+def _read_index(f):
+    fourcc = f.read(4)
+    if fourcc in (b"IxFI", b"IxF2"):
+        d, ntotal, metric = _r_header(f)
+        xb = _r_vec(f, np.float32)
+        if xb.size != ntotal * d:
+            raise RuntimeError("read_index: IndexFlat payload size mismatch")
+        idx = IndexFlat(d, metric)
+        if ntotal:
+            idx.add(np.ascontiguousarray(xb.reshape(ntotal, d)))
+        return idx
+    if fourcc == b"IHNf":
+        d, ntotal, metric = _r_header(f)
+        probas = _r_vec(f, np.float64)
+        cum = _r_vec(f, np.int32)
+        levels = _r_vec(f, np.int32)
+        offsets = _r_vec(f, np.uint64)
+        nbrs = _r_vec(f, np.int32)
+        entry, max_level, efc, efs, _upper = _struct.unpack("<iiiii", f.read(20))
+        storage = _read_index(f)
+        M = int(cum[2] - cum[1]) if cum.size > 2 else int(cum[1] // 2)
+        idx = IndexHNSWFlat(d, M, metric)
+        L = _lib.lib()
+        rows = storage.reconstruct_n(0, ntotal) if ntotal else np.empty((0, d), np.float32)
+        if ntotal:
+            _lib.check(L.knn_flat_add(L.knn_hnsw_storage(idx._h), rows.ctypes.data, ntotal))
+        lv = np.ascontiguousarray(levels - 1, np.int32)
+        nb = np.ascontiguousarray(nbrs, np.int32)
+        _lib.check(L.knn_hnsw_graph_import(idx._h, ntotal, lv.ctypes.data, nb.ctypes.data, nb.size, max_level, entry))
+        _lib.check(L.knn_hnsw_set_ef(idx._h, efs, efc))
+        return idx
+    if fourcc == b"IxHe":
+        from .lsh import IndexLSH
+        return IndexLSH._read(f)
+    raise RuntimeError(f"read_index: unsupported index type {fourcc!r}")

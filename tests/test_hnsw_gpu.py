@@ -1,0 +1,149 @@
+"""GPU: IndexHNSWFlat (host graph walk, GPU distances).  FAISS's own HNSW graph is not
+deterministic under OpenMP, so parity is stated the way the north star does: recall@k
+against the exact flat search, plus bit-equality of every returned distance with the flat
+kernel's distance for the same (query, row)."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _clustered(n, d, ncent, seed):
+    rng = np.random.default_rng(seed)
+    cent = rng.standard_normal((ncent, d), dtype=np.float32)
+    x = cent[rng.integers(0, ncent, n)] + 0.35 * rng.standard_normal((n, d), dtype=np.float32)
+    return x
+
+
+def _recall(I, It):
+    return sum(len(np.intersect1d(a[a >= 0], b)) for a, b in zip(I, It)) / It.size
+
+
+def test_fixture_exact_when_ef_exceeds_ntotal(gpu_faiss, oracle):
+    """pfam-20-10 (200 rows): ef = 256 >= ntotal, so the walk visits the whole connected
+    graph and must return exactly the flat result (reference setting: M = 42, inner
+    product, efSearch = 256 -- pfam/proteins_search.py:30-31)."""
+    x = np.load(GOLDEN / "pfam-20-10" / "train.npy")
+    q = np.load(GOLDEN / "pfam-20-10" / "test.npy")
+    gpu_faiss.normalize_L2(x)
+    gpu_faiss.normalize_L2(q)
+    idx = gpu_faiss.IndexHNSWFlat(1024, 42, gpu_faiss.METRIC_INNER_PRODUCT)
+    idx.hnsw.efSearch = 256
+    idx.train(x)
+    idx.add(x)
+    assert idx.ntotal == 200 and idx.hnsw.efSearch == 256 and idx.hnsw.M == 42
+    D, I = idx.search(q, 10)
+    Do, Io = oracle.flat_search(x, q, 10, 0)
+    assert np.array_equal(I, Io) and np.array_equal(D.view(np.uint32), Do.view(np.uint32))
+    # k > ntotal: the tail is id -1
+    D, I = idx.search(q[:3], 230)
+    assert (I[:, 200:] == -1).all() and (np.sort(I[:, :200], axis=1) == np.arange(200)).all()
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_recall_and_distance_bits(gpu_faiss, metric):
+    n, d, nq = 20000, 256, 1000
+    x = _clustered(n, d, 200, 21)
+    gpu_faiss.normalize_L2(x)
+    flat = gpu_faiss.IndexFlat(d, metric)
+    flat.add(x)
+    Dt, It = flat.search(x[:nq], 100)
+    idx = gpu_faiss.IndexHNSWFlat(d, 32, metric)
+    idx.add(x)
+    idx.hnsw.efSearch = 256
+    D, I = idx.search(x[:nq], 100)
+    assert _recall(I, It) >= 0.97
+    # every returned (id, distance) equals the flat kernel's value for that pair, bit for bit
+    full = gpu_faiss.IndexFlat(d, metric)
+    full.add(x)
+    Dall, Iall = full.search(x[:16], 2048)
+    for qi in range(16):
+        ref = dict(zip(Iall[qi].tolist(), Dall[qi].view(np.uint32).tolist()))
+        for j, v in zip(I[qi].tolist(), D[qi].view(np.uint32).tolist()):
+            if j in ref:
+                assert ref[j] == v
+    # order: best first, ties by id
+    if metric == 0:
+        assert (np.diff(D, axis=1) <= 0).all()
+    else:
+        assert (np.diff(D, axis=1) >= 0).all()
+    # efSearch trades recall for work
+    idx.hnsw.efSearch = 16
+    _, I16 = idx.search(x[:nq], 10)
+    idx.hnsw.efSearch = 128
+    _, I128 = idx.search(x[:nq], 10)
+    assert _recall(I128, It[:, :10]) >= _recall(I16, It[:, :10]) >= 0.8
+
+
+def test_graph_invariants_and_determinism(gpu_faiss):
+    n, d, M = 6000, 64, 16
+    x = _clustered(n, d, 50, 5)
+    a = gpu_faiss.IndexHNSWFlat(d, M, 1)
+    a.add(x)
+    levels, offsets, nbrs, cum, probas = a.graph()
+    assert levels.shape == (n,) and offsets[-1] == nbrs.size and cum[1] == 2 * M and cum[2] - cum[1] == M
+    assert levels.max() == a.hnsw.max_level and levels[a.hnsw.entry_point] == levels.max()
+    assert nbrs.max() < n and nbrs.min() >= -1
+    # level populations fall roughly geometrically
+    assert (levels >= 1).mean() < 0.15
+    for i in range(0, n, 37):
+        for l in range(levels[i] + 1):
+            lst = nbrs[offsets[i] + cum[l]: offsets[i] + cum[l + 1]]
+            used = lst[lst >= 0]
+            assert (lst[len(used):] == -1).all(), "neighbour lists are packed to the front"
+            assert i not in used and len(set(used.tolist())) == len(used)
+            assert (levels[used] >= l).all(), "links stay inside their level"
+    # the build is deterministic (batch-synchronous), two adds give the same result as one
+    b = gpu_faiss.IndexHNSWFlat(d, M, 1)
+    b.add(x)
+    assert np.array_equal(b.graph()[2], nbrs)
+
+
+def test_write_read_index_roundtrip(gpu_faiss, tmp_path):
+    n, d = 3000, 96
+    x = _clustered(n, d, 30, 9)
+    for make in (lambda: gpu_faiss.IndexFlat(d, 0), lambda: gpu_faiss.IndexFlat(d, 1),
+                 lambda: gpu_faiss.IndexHNSWFlat(d, 12, 1)):
+        idx = make()
+        idx.add(x)
+        f = tmp_path / "i.index"
+        gpu_faiss.write_index(idx, str(f))
+        raw = f.read_bytes()
+        assert raw[:4] in (b"IxFI", b"IxF2", b"IHNf")
+        back = gpu_faiss.read_index(str(f))
+        assert type(back) is type(idx) and back.ntotal == n and back.d == d and back.metric_type == idx.metric_type
+        if isinstance(idx, gpu_faiss.IndexHNSWFlat):
+            idx.hnsw.efSearch = back.hnsw.efSearch = 64
+        D0, I0 = idx.search(x[:50], 10)
+        D1, I1 = back.search(x[:50], 10)
+        assert np.array_equal(I0, I1) and np.array_equal(D0, D1)
+    # IndexFlat file layout: fourcc, d, ntotal, 2 dummies, is_trained, metric, count, floats
+    idx = gpu_faiss.IndexFlat(d, 1)
+    idx.add(x[:5])
+    gpu_faiss.write_index(idx, str(f))
+    raw = f.read_bytes()
+    assert len(raw) == 4 + 4 + 8 * 3 + 1 + 4 + 8 + 5 * d * 4
+    assert np.array_equal(np.frombuffer(raw[-5 * d * 4:], np.float32).reshape(5, d), x[:5])
+
+
+def test_proteins_search_entry_point(gpu_faiss, tmp_path, capsys):
+    """pfam/proteins_search.py:11-57 protocol on a fixture-sized 'full_sequences.npy'."""
+    from knn_for_homology_amd.pfam import proteins_search
+    x = np.load(GOLDEN / "pfam-20-dist" / "test.npy")
+    np.save(tmp_path / "full_sequences.npy", x.astype(np.float16))  # the script casts to float32
+    for mode in ("flat", "hnsw"):
+        proteins_search.main(["prog", mode], data_dir=tmp_path, k=50)
+        out = capsys.readouterr().out
+        assert "full_sequences (210, 1024)" in out and "Index creation took" in out and "Search took" in out
+        assert "Embeddings:" in out and "Index:" in out and "Difference:" in out
+        scores = np.load(tmp_path / f"full_sequences_{mode}_scores.npy")
+        hits = np.load(tmp_path / f"full_sequences_{mode}_hits.npy")
+        assert scores.shape == (210, 50) and scores.dtype == np.float32 and hits.dtype == np.int64
+        assert (hits[:, 0] == np.arange(210)).all(), "self hit first (pfam/proteins.py:85-122 relies on it)"
+        assert (tmp_path / f"full_sequences_{mode}.index").stat().st_size > 210 * 1024 * 4
+    flat_hits = np.load(tmp_path / "full_sequences_flat_hits.npy")
+    assert np.array_equal(flat_hits, np.load(tmp_path / "full_sequences_hnsw_hits.npy"))
+    with pytest.raises(ValueError):
+        proteins_search.main(["prog", "ivf"], data_dir=tmp_path)
