@@ -133,6 +133,23 @@ int knn_hnsw_graph_import(knn_hnsw_handle h, int64_t ntotal, const int32_t *leve
 int knn_hnsw_stats(knn_hnsw_handle h, int64_t *pairs, int64_t *rounds, int64_t *shrinks, double *gpu_s,
                    double *host_s, int32_t reset);
 
+/* ---- faiss.IndexLSH(d, nbits) -----------------------------------------------
+ * seqvec_search/create_index.py:41-45, pfam/search.py:27-37, pfam/proteins_search.py:25-26.
+ * rotation_host: [nbits][d] row-major projection rows (FAISS uses a random orthonormal
+ * matrix from its own RNG; the caller supplies one).  Codes: bit j = (x . rot_j >= 0);
+ * search returns the k smallest Hamming distances as float32, ties by lower id. */
+typedef struct knn_lsh_s *knn_lsh_handle;
+int knn_lsh_create(int32_t d, int32_t nbits, const float *rotation_host, knn_lsh_handle *out);
+int knn_lsh_add(knn_lsh_handle h, const float *x_host, int64_t n);
+int knn_lsh_search(knn_lsh_handle h, const float *q_host, int64_t nq, int64_t k, float *D_host,
+                   int64_t *I_host);
+int64_t knn_lsh_ntotal(knn_lsh_handle h);
+int32_t knn_lsh_code_words(knn_lsh_handle h);
+/* codes in FAISS byte order ([ntotal][bytes_per_vec], bit i -> byte i>>3, bit i&7) */
+int knn_lsh_get_codes(knn_lsh_handle h, uint8_t *out_host, int32_t bytes_per_vec);
+int knn_lsh_add_codes(knn_lsh_handle h, const uint8_t *codes_host, int64_t n, int32_t bytes_per_vec);
+void knn_lsh_free(knn_lsh_handle h);
+
 /* ---- distances for explicit candidate lists (HNSW walk offload) --------
  * For query i (row of q_dev [nq,d]) and candidates cand[off[i] .. off[i+1]),
  * out[p] = <q,y> (IP) or max(0, |q|^2+|y|^2-2<q,y>) (L2), same arithmetic as

@@ -63,6 +63,14 @@ def _declare(L):
         "knn_hnsw_graph_export": (c_int32, [H, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
         "knn_hnsw_graph_import": (c_int32, [H, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_int64]),
         "knn_hnsw_stats": (c_int32, [H, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), POINTER(ctypes.c_double), POINTER(ctypes.c_double), c_int32]),
+        "knn_lsh_create": (c_int32, [c_int32, c_int32, c_void_p, POINTER(H)]),
+        "knn_lsh_add": (c_int32, [H, c_void_p, c_int64]),
+        "knn_lsh_search": (c_int32, [H, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+        "knn_lsh_ntotal": (c_int64, [H]),
+        "knn_lsh_code_words": (c_int32, [H]),
+        "knn_lsh_get_codes": (c_int32, [H, c_void_p, c_int32]),
+        "knn_lsh_add_codes": (c_int32, [H, c_void_p, c_int64, c_int32]),
+        "knn_lsh_free": (None, [H]),
         "knn_scan_times": (c_int32, [H, c_void_p, c_int32]),
         "knn_flat_reserve": (c_int32, [H, c_int64]),
     }

@@ -331,6 +331,107 @@ struct ScanParams {
     int dbg;           // timing experiments only: 2 = skip compaction, 4 = skip appends
 };
 
+// ---- per-workgroup candidate lists shared by the scan kernels -------------------------
+// s_thr / s_cnt / s_need live in LDS, the lists themselves in global memory (L2).
+struct ListCtx {
+    float *s_thr;     // [QT] local admission threshold (value of the loosest kept key)
+    int *s_cnt;       // [QT] list fill
+    int *s_need;      // some list could overflow on the next tile
+    uint64_t *lists;  // [QT][cap] this workgroup's lists
+    uint32_t *gthr;   // [QT] shared running thresholds of these queries
+    int cap, k;
+
+    __device__ __forceinline__ void init(int tid, int QT)
+    {
+        for (int i = tid; i < QT; i += 256) {
+            s_thr[i] = INFINITY;
+            s_cnt[i] = 0;
+        }
+        if (tid == 0) *s_need = 0;
+    }
+    __device__ __forceinline__ float threshold(int ql) const
+    {
+        const uint32_t g = __hip_atomic_load(&gthr[ql], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return fminf(s_thr[ql], ord2f(g));
+    }
+    // v: "smaller is better" score of row `id` for local query ql (caller checked v <= threshold)
+    __device__ __forceinline__ void append(int ql, float v, uint32_t id, int tile_rows)
+    {
+        v = v + 0.0f;
+        const int slot = atomicAdd(&s_cnt[ql], 1);
+        if (slot < cap) lists[(size_t)ql * cap + slot] = ((uint64_t)f2ord(v) << 32) | id;
+        if (slot + 1 > cap - tile_rows) *s_need = 1;
+    }
+};
+
+// Called by all 256 threads after a tile's appends (and a barrier).  Lists that could
+// overflow on the next tile are cut back to [k, 1.25k] keys; on the last tile every list is
+// cut to exactly k and written (unsorted) to out_base + ql * out_stride.
+template <int QT>
+__device__ __forceinline__ void lists_compact(ListCtx &L, char *smem, int tile_rows, bool last_tile, int64_t nq_valid,
+                                              uint64_t *out_base, size_t out_stride, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    const int R = L.cap >> 6;
+    if (R <= 64) {
+        // one wave per query, registers only: four queries in flight per workgroup
+        for (int ql = wave; ql < QT; ql += 4) {
+            const int n = __builtin_amdgcn_readfirstlane(min(L.s_cnt[ql], L.cap));
+            uint64_t *lst = L.lists + (size_t)ql * L.cap;
+            uint32_t T = 0;
+            if (!last_tile) {
+                if (n <= L.cap - tile_rows) continue;
+                const int cnt = wave_select_dispatch(R, LoadContig{lst}, n, L.k, L.k + (L.k >> 2), lane, &T, lst);
+                if (lane == 0) {
+                    L.s_cnt[ql] = cnt;
+                    L.s_thr[ql] = ord2f(T);
+                    atomicMin(&L.gthr[ql], T);
+                }
+            } else {
+                if (ql >= nq_valid) continue;
+                uint64_t *out = out_base + (size_t)ql * out_stride;
+                if (n > L.k) {
+                    wave_select_dispatch(R, LoadContig{lst}, n, L.k, L.k, lane, &T, out); // exactly k, unsorted
+                    if (lane == 0) atomicMin(&L.gthr[ql], T);
+                } else {
+                    for (int i = lane; i < L.k; i += 64) out[i] = i < n ? lst[i] : KEY_PAD;
+                }
+            }
+        }
+        __syncthreads();
+    } else {
+        // k close to KNN_MAX_K: lists too long for registers, whole-workgroup LDS sort
+        uint64_t *sb = (uint64_t *)smem;
+        for (int ql = 0; ql < QT; ql++) {
+            const int n = min(L.s_cnt[ql], L.cap);
+            if (!last_tile && n <= L.cap - tile_rows) continue;
+            uint64_t *lst = L.lists + (size_t)ql * L.cap;
+            const int P = next_pow2_dev(n > 0 ? n : 1);
+            for (int i = tid; i < P; i += 256) sb[i] = i < n ? lst[i] : KEY_PAD;
+            __syncthreads();
+            wg_bitonic_sort(sb, P, tid, 256);
+            const int keep = min(n, L.k);
+            if (!last_tile) {
+                for (int i = tid; i < keep; i += 256) lst[i] = sb[i];
+            } else if (ql < nq_valid) {
+                uint64_t *out = out_base + (size_t)ql * out_stride;
+                for (int i = tid; i < L.k; i += 256) out[i] = i < keep ? sb[i] : KEY_PAD;
+            }
+            if (tid == 0) {
+                L.s_cnt[ql] = keep;
+                if (n >= L.k) {
+                    const uint32_t o = (uint32_t)(sb[L.k - 1] >> 32);
+                    L.s_thr[ql] = ord2f(o);
+                    atomicMin(&L.gthr[ql], o);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) *L.s_need = 0;
+    __syncthreads();
+}
+
 template <bool GLDS>
 __device__ __forceinline__ void stage_issue(const float *src, char *lds_wave_base, int lane, f32x4 &reg)
 {
@@ -357,9 +458,6 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
     char *stage0 = smem;
     char *stage1 = smem + STAGE_BYTES;
     const int lds_main = max(2 * STAGE_BYTES, p.cap * 8);
-    float *s_thr = (float *)(smem + lds_main);
-    int *s_cnt = (int *)(s_thr + QT);
-    int *s_need = s_cnt + QT;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -372,14 +470,16 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
     const int64_t q0 = (int64_t)qtile * QT;
     const int64_t c_lo = (int64_t)chunk * p.chunk_rows;
     const int64_t c_hi = min(p.nb, c_lo + p.chunk_rows);
-    uint64_t *my_lists = p.lists + (size_t)blockIdx.x * QT * p.cap;
     const int KT = p.dp / 32;
-
-    for (int i = tid; i < QT; i += 256) {
-        s_thr[i] = INFINITY;
-        s_cnt[i] = 0;
-    }
-    if (tid == 0) *s_need = 0;
+    ListCtx L;
+    L.s_thr = (float *)(smem + lds_main);
+    L.s_cnt = (int *)(L.s_thr + QT);
+    L.s_need = L.s_cnt + QT;
+    L.lists = p.lists + (size_t)blockIdx.x * QT * p.cap;
+    L.gthr = p.gthr + (size_t)qtile * QT;
+    L.cap = p.cap;
+    L.k = p.k;
+    L.init(tid, QT);
     __syncthreads();
 
     // per-lane staging bookkeeping: instruction ii covers combined rows 8*ii..8*ii+7
@@ -479,11 +579,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
             const int ql = (wn * TN + b) * 32 + li;
             const int64_t q = q0 + ql;
             const bool qok = q < p.nq;
-            float thr = s_thr[ql];
-            {
-                uint32_t g = __hip_atomic_load(&p.gthr[qtile * QT + ql], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                thr = fminf(thr, ord2f(g));
-            }
+            const float thr = L.threshold(ql);
             float xnq = 0.0f;
             if constexpr (L2) xnq = p.xn[qok ? q : 0];
 #pragma unroll
@@ -501,14 +597,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
                     } else {
                         v = -acc[a][b][r];
                     }
-                    if (v <= thr && row < c_hi && qok && !(p.dbg & 4)) {
-                        v = v + 0.0f;
-                        int slot = atomicAdd(&s_cnt[ql], 1);
-                        if (slot < p.cap)
-                            my_lists[(size_t)ql * p.cap + slot] =
-                                ((uint64_t)f2ord(v) << 32) | (uint32_t)(p.id_base + (uint32_t)row);
-                        if (slot + 1 > p.cap - DT) *s_need = 1;
-                    }
+                    if (v <= thr && row < c_hi && qok && !(p.dbg & 4)) L.append(ql, v, p.id_base + (uint32_t)row, DT);
                 }
             }
         }
@@ -516,68 +605,9 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 
         // ---- compaction of lists that could overflow on the next tile ----
         const bool last_tile = row0 + DT >= c_hi;
-        if ((*s_need || last_tile) && !(p.dbg & 2)) {
-            const int R = p.cap >> 6;
-            if (R <= 64) {
-                // one wave per query, registers only: four queries in flight per workgroup
-                for (int ql = wave; ql < QT; ql += 4) {
-                    const int n = __builtin_amdgcn_readfirstlane(min(s_cnt[ql], p.cap));
-                    uint64_t *lst = my_lists + (size_t)ql * p.cap;
-                    uint32_t T = 0;
-                    if (!last_tile) {
-                        if (n <= p.cap - DT) continue;
-                        const int cnt = wave_select_dispatch(R, LoadContig{lst}, n, p.k, p.k + (p.k >> 2), lane, &T, lst);
-                        if (lane == 0) {
-                            s_cnt[ql] = cnt;
-                            s_thr[ql] = ord2f(T);
-                            atomicMin(&p.gthr[qtile * QT + ql], T);
-                        }
-                    } else {
-                        const int64_t q = q0 + ql;
-                        if (q >= p.nq) continue;
-                        uint64_t *out = p.partial + ((size_t)q * p.nchunks + chunk) * p.k;
-                        if (n > p.k) {
-                            wave_select_dispatch(R, LoadContig{lst}, n, p.k, p.k, lane, &T, out); // exactly k, unsorted
-                            if (lane == 0) atomicMin(&p.gthr[qtile * QT + ql], T);
-                        } else {
-                            for (int i = lane; i < p.k; i += 64) out[i] = i < n ? lst[i] : KEY_PAD;
-                        }
-                    }
-                }
-                __syncthreads();
-            } else {
-                // k close to KNN_MAX_K: lists too long for registers, whole-workgroup LDS sort
-                uint64_t *sb = (uint64_t *)smem;
-                for (int ql = 0; ql < QT; ql++) {
-                    const int n = min(s_cnt[ql], p.cap);
-                    if (!last_tile && n <= p.cap - DT) continue;
-                    const int64_t q = q0 + ql;
-                    uint64_t *lst = my_lists + (size_t)ql * p.cap;
-                    const int P = next_pow2_dev(n > 0 ? n : 1);
-                    for (int i = tid; i < P; i += 256) sb[i] = i < n ? lst[i] : KEY_PAD;
-                    __syncthreads();
-                    wg_bitonic_sort(sb, P, tid, 256);
-                    const int keep = min(n, p.k);
-                    if (!last_tile) {
-                        for (int i = tid; i < keep; i += 256) lst[i] = sb[i];
-                    } else if (q < p.nq) {
-                        uint64_t *out = p.partial + ((size_t)q * p.nchunks + chunk) * p.k;
-                        for (int i = tid; i < p.k; i += 256) out[i] = i < keep ? sb[i] : KEY_PAD;
-                    }
-                    if (tid == 0) {
-                        s_cnt[ql] = keep;
-                        if (n >= p.k) {
-                            uint32_t o = (uint32_t)(sb[p.k - 1] >> 32);
-                            s_thr[ql] = ord2f(o);
-                            atomicMin(&p.gthr[qtile * QT + ql], o);
-                        }
-                    }
-                    __syncthreads();
-                }
-            }
-            if (tid == 0) *s_need = 0;
-            __syncthreads();
-        }
+        if ((*L.s_need || last_tile) && !(p.dbg & 2))
+            lists_compact<QT>(L, smem, DT, last_tile, p.nq - q0, p.partial + ((size_t)q0 * p.nchunks + chunk) * p.k,
+                              (size_t)p.nchunks * p.k, tid);
     }
 }
 
@@ -1433,3 +1463,4 @@ extern "C" int knn_gather_distances(knn_handle h, const float *q_host, int64_t n
 }
 
 #include "hnsw.inc"
+#include "lsh.inc"

@@ -363,3 +363,10 @@ def _read_index(f):
         from .lsh import IndexLSH
         return IndexLSH._read(f)
     raise RuntimeError(f"read_index: unsupported index type {fourcc!r}")
+
+
+def __getattr__(name):  # IndexLSH lives in lsh.py (it imports this module)
+    if name == "IndexLSH":
+        from .lsh import IndexLSH
+        return IndexLSH
+    raise AttributeError(name)
