@@ -63,9 +63,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    use_pg = world > 1 or os.environ.get("KNN355_FORCE_COLLECTIVE", "0") == "1"
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from knn_for_homology_amd import _lib, faiss
     from knn_for_homology_amd.sharded import ShardedFlatIndex, shard_bounds
@@ -127,8 +129,7 @@ def main():
     avg_scan_ms = float(np.mean(scan_ms)) if scan_ms else None
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     ms_per_step = 1e3 * elapsed / args.steps
@@ -159,7 +160,10 @@ def main():
         tfile = ROOT / "profiles" / "pmc_traffic.json"
         if tfile.exists():
             try:
-                traffic = json.loads(tfile.read_text()).get(info["kernel"], {}).get("hbm_bytes_per_launch")
+                rec = json.loads(tfile.read_text()).get(info["kernel"], {})
+                # the counters were collected on the default workload: only quote them for it
+                if rec.get("algorithmic_bytes_per_launch") == alg_bytes:
+                    traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out["roofline"] = {
@@ -177,7 +181,7 @@ def main():
         torch.cuda.empty_cache()
         out["batch"] = batch_config(dev, L, _lib, faiss)
     print(json.dumps(out))
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 

@@ -277,10 +277,12 @@ __device__ __attribute__((noinline)) int wave_select(LD load, int n, int k, int 
             if (wave_sum(c) <= need - 1) Q = Qt;
         }
     }
-    // survivors: lane-major packing (order inside a list is irrelevant)
+    // survivors: lane-major packing (order inside a list is irrelevant).  When the cut falls
+    // into the padding (fewer than k real keys) only real keys survive; the caller pads.
+    const bool tie_ok = T != 0xFFFFFFFFu;
     int mine = 0;
 #pragma unroll
-    for (int r = 0; r < R; r++) mine += (hi[r] < Tlt || (hi[r] == T && lo[r] <= Q)) ? 1 : 0;
+    for (int r = 0; r < R; r++) mine += (hi[r] < Tlt || (hi[r] == T && tie_ok && lo[r] <= Q)) ? 1 : 0;
     int incl = mine;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -291,7 +293,7 @@ __device__ __attribute__((noinline)) int wave_select(LD load, int n, int k, int 
     const int total = __shfl(incl, 63, 64);
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        if (hi[r] < Tlt || (hi[r] == T && lo[r] <= Q)) {
+        if (hi[r] < Tlt || (hi[r] == T && tie_ok && lo[r] <= Q)) {
             if (pos < kmax) dst[pos] = ((uint64_t)hi[r] << 32) | lo[r];
             pos++;
         }
@@ -328,6 +330,9 @@ struct ScanParams {
     uint32_t *gthr;    // [nqtiles*QT] shared running thresholds (order-mapped floats)
     uint64_t *partial; // [nq][nchunks][k]
     uint32_t id_base;
+    int row_mul;       // this launch scans the strided view rows r*row_mul (r < nb)
+    int skip_mask;     // >= 0: rows with (r & skip_mask) == 0 belong to the seed sample, skip them
+    int partial_lists; // lists per query in `partial` (nchunks, +1 when a seed list rides along)
     int dbg;           // timing experiments only: 2 = skip compaction, 4 = skip appends
 };
 
@@ -522,7 +527,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 #pragma unroll
         for (int n = 0; n < NI; n++) {
             if (is_db[n]) {
-                int64_t r = min(row0 + rloc[n], p.nb - 1);
+                int64_t r = min(row0 + rloc[n], p.nb - 1) * p.row_mul;
                 tsrc[n] = srcp[n] + r * p.dp;
             } else {
                 tsrc[n] = srcp[n];
@@ -590,14 +595,15 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
                     const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
                     float v;
                     if constexpr (L2) {
-                        float ynr = p.yn[min(row, p.nb - 1)];
+                        float ynr = p.yn[min(row, p.nb - 1) * p.row_mul];
                         float t = xnq + ynr;
                         v = __builtin_fmaf(-2.0f, acc[a][b][r], t);
                         v = v < 0.0f ? 0.0f : v;
                     } else {
                         v = -acc[a][b][r];
                     }
-                    if (v <= thr && row < c_hi && qok && !(p.dbg & 4)) L.append(ql, v, p.id_base + (uint32_t)row, DT);
+                    if (v <= thr && row < c_hi && qok && !(p.skip_mask >= 0 && ((int)row & p.skip_mask) == 0) && !(p.dbg & 4))
+                        L.append(ql, v, p.id_base + (uint32_t)row * (uint32_t)p.row_mul, DT);
                 }
             }
         }
@@ -606,9 +612,18 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
         // ---- compaction of lists that could overflow on the next tile ----
         const bool last_tile = row0 + DT >= c_hi;
         if ((*L.s_need || last_tile) && !(p.dbg & 2))
-            lists_compact<QT>(L, smem, DT, last_tile, p.nq - q0, p.partial + ((size_t)q0 * p.nchunks + chunk) * p.k,
-                              (size_t)p.nchunks * p.k, tid);
+            lists_compact<QT>(L, smem, DT, last_tile, p.nq - q0, p.partial + ((size_t)q0 * p.partial_lists + chunk) * p.k,
+                              (size_t)p.partial_lists * p.k, tid);
     }
+}
+
+// gthr[q] <- score word of the k-th seed key (padding reads as "no bound")
+__global__ void seed_thresholds_kernel(const uint64_t *__restrict__ seed_keys, int64_t key_stride, int k, int64_t nq,
+                                       int64_t nslots, uint32_t *__restrict__ gthr)
+{
+    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nslots) return;
+    gthr[q] = q < nq ? (uint32_t)(seed_keys[q * key_stride + (k - 1)] >> 32) : 0xFFFFFFFFu;
 }
 
 // ---------------------------------------------------------------------------
@@ -622,8 +637,8 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 template <bool LISTMAJOR>
 __global__ __launch_bounds__(256) void merge_select_kernel(const uint64_t *__restrict__ in, int L, int k, int64_t nq,
                                                            int G, int Lout, uint64_t *__restrict__ out_keys,
-                                                           int final_round, int metric, float *__restrict__ D,
-                                                           int64_t *__restrict__ I)
+                                                           int64_t out_key_stride, int final_round, int metric,
+                                                           float *__restrict__ D, int64_t *__restrict__ I)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -675,7 +690,7 @@ __global__ __launch_bounds__(256) void merge_select_kernel(const uint64_t *__res
     for (int i = lane; i < k; i += 64) {
         const uint64_t key = sb[i];
         const size_t o = (size_t)q * k + i;
-        if (out_keys) out_keys[o] = key;
+        if (out_keys) out_keys[(size_t)q * out_key_stride + i] = key;
         if (D) {
             if (key == KEY_PAD) {
                 D[o] = metric == KNN_METRIC_INNER_PRODUCT ? -FLT_MAX : FLT_MAX;
@@ -792,6 +807,8 @@ struct knn_index_s {
     int64_t nlaunches = 0;
     std::mutex mu;
     DevBuf ws_q, ws_qn, ws_lists, ws_gthr, ws_partial, ws_partial2, ws_keys, ws_D, ws_I, ws_tmp, ws_tmp2;
+    DevBuf ws_level[8]; // per seed-recursion level: [nq][lists][k] survivor keys
+    int last_seed_stride = 0;
     // tuning + introspection
     int force_qt = 0, force_chunks = 0, flags = 0;
     std::string last_kernel;
@@ -929,6 +946,7 @@ extern "C" void knn_free(knn_handle h)
         DevBuf *bufs[] = {&h->ws_q, &h->ws_qn, &h->ws_lists, &h->ws_gthr, &h->ws_partial, &h->ws_partial2,
                           &h->ws_keys, &h->ws_D, &h->ws_I, &h->ws_tmp, &h->ws_tmp2};
         for (DevBuf *b : bufs) b->release();
+        for (DevBuf &b : h->ws_level) b.release();
         for (int i = 0; i < knn_index_s::RING; i++) {
             if (h->ring0[i]) (void)hipEventDestroy(h->ring0[i]);
             if (h->ring1[i]) (void)hipEventDestroy(h->ring1[i]);
@@ -1074,8 +1092,9 @@ static int next_pow2_host(int n)
 // the last round sorts and writes keys_out (may be null) and/or D/I (may be null).
 // tmp0/tmp1: ping-pong buffers for intermediate rounds.
 static int run_merge(const uint64_t *in, int L, int k, int64_t nq, bool list_major, DevBuf &tmp0, DevBuf &tmp1,
-                     uint64_t *keys_out, int metric, float *D, int64_t *I, hipStream_t s)
+                     uint64_t *keys_out, int metric, float *D, int64_t *I, hipStream_t s, int64_t keys_out_stride = 0)
 {
+    if (keys_out_stride == 0) keys_out_stride = k;
     const int G = std::max(2, 4096 / k);
     const size_t lds_final = (size_t)4 * next_pow2_host(k) * 8;
     bool lm = list_major;
@@ -1097,11 +1116,11 @@ static int run_merge(const uint64_t *in, int L, int k, int64_t nq, bool list_maj
         if (lm) {
             if (lds > 65536) HIP_TRY(hipFuncSetAttribute((const void *)merge_select_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(merge_select_kernel<true>, dim3(grid), dim3(256), lds, s, in, L, k, nq, G, Lout, out,
-                               final_round ? 1 : 0, metric, D, I);
+                               final_round ? keys_out_stride : (int64_t)0, final_round ? 1 : 0, metric, D, I);
         } else {
             if (lds > 65536) HIP_TRY(hipFuncSetAttribute((const void *)merge_select_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(merge_select_kernel<false>, dim3(grid), dim3(256), lds, s, in, L, k, nq, G, Lout, out,
-                               final_round ? 1 : 0, metric, D, I);
+                               final_round ? keys_out_stride : (int64_t)0, final_round ? 1 : 0, metric, D, I);
         }
         HIP_TRY(hipGetLastError());
         if (final_round) return 0;
@@ -1136,7 +1155,7 @@ static int launch_scan_cfg(const knn_index_s *h, const ScanParams &p, const Scan
     return 0;
 }
 
-static void make_plan(const knn_index_s *h, int64_t nq, int k, ScanPlan &pl)
+static void make_plan(const knn_index_s *h, int64_t nb, int64_t nq, int k, bool seeded, ScanPlan &pl)
 {
     int qt = h->force_qt;
     if (qt != 32 && qt != 64 && qt != 128) qt = nq <= 32 ? 32 : (nq <= 64 ? 64 : 128);
@@ -1146,11 +1165,12 @@ static void make_plan(const knn_index_s *h, int64_t nq, int k, ScanPlan &pl)
     pl.nqtiles = (int)((nq + qt - 1) / qt);
     pl.cap = next_pow2_host(2 * k + pl.dt);
     if (pl.cap < 512) pl.cap = 512;
-    const int64_t ntiles = (h->ntotal + pl.dt - 1) / pl.dt;
+    const int64_t ntiles = (nb + pl.dt - 1) / pl.dt;
     int64_t want = h->force_chunks > 0 ? h->force_chunks : (1024 + pl.nqtiles - 1) / pl.nqtiles;
-    // each chunk should see enough rows to amortise its threshold warm-up
+    // an unseeded chunk should see enough rows to amortise its threshold warm-up; a seeded pass
+    // starts with good thresholds and a tiny view (a seed sample) just wants parallelism
     int64_t min_tiles = std::max<int64_t>(2, (4 * (int64_t)k + pl.dt - 1) / pl.dt);
-    if (h->force_chunks <= 0) want = std::min(want, std::max<int64_t>(1, ntiles / min_tiles));
+    if (h->force_chunks <= 0 && !seeded && nb >= 8192) want = std::min(want, std::max<int64_t>(1, ntiles / min_tiles));
     want = std::max<int64_t>(1, std::min(want, ntiles));
     // bound the candidate-list workspace (<= 2 GiB)
     const size_t per_wg = (size_t)qt * pl.cap * 8;
@@ -1158,38 +1178,75 @@ static void make_plan(const knn_index_s *h, int64_t nq, int k, ScanPlan &pl)
     want = std::max<int64_t>(1, std::min(want, max_wgs / pl.nqtiles));
     int64_t tiles_per = (ntiles + want - 1) / want;
     pl.chunk_rows = tiles_per * pl.dt;
-    pl.nchunks = (int)((h->ntotal + pl.chunk_rows - 1) / pl.chunk_rows);
+    pl.nchunks = (int)((nb + pl.chunk_rows - 1) / pl.chunk_rows);
     pl.grid = pl.nqtiles * pl.nchunks;
     pl.lds = std::max((size_t)2 * (pl.dt + pl.qt) * 128, (size_t)pl.cap * 8) + (size_t)qt * 8 + 16;
 }
 
-// queries [nq][dp] already on device (padded); writes sorted keys [nq][k]
-static int search_keys_impl(knn_index_s *h, const float *q_dev, int64_t nq, int k, uint32_t id_base,
-                            uint64_t *keys_out, float *D_out, int64_t *I_out, hipStream_t s)
+// Seed stride of a view with nb rows: a power of two s such that the sample (every s-th row)
+// has about max(2 * chunk_rows, 64 k) rows (and at most nb/8).  The sample is searched first,
+// exactly; its k-th score bounds the global k-th from above, so every chunk of the main pass
+// starts with a tight threshold and appends about chunk_rows * k / sample_rows <= k/2
+// candidates per query instead of warming up (and compacting) on its own.
+static int seed_stride(int64_t nb, int k, int64_t chunk_rows)
 {
+    const int64_t target = std::min<int64_t>(std::max<int64_t>(2 * chunk_rows, 64 * (int64_t)k), nb / 8);
+    int s = 8;
+    while ((int64_t)s * 2 * target <= nb && s < (1 << 20)) s *= 2;
+    return s;
+}
+
+// Exact top-k of the strided view {r * row_mul : r < ceil(ntotal / row_mul)} for queries
+// [nq][dp] on the device.  Output: sorted keys (keys_out, per-query stride keys_stride) and/or D/I.
+static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int64_t nq, int k, uint32_t id_base, int row_mul,
+                       int level, uint64_t *keys_out, int64_t keys_stride, float *D_out, int64_t *I_out, hipStream_t s)
+{
+    const int64_t nb = (h->ntotal + row_mul - 1) / row_mul;
     ScanPlan pl;
-    make_plan(h, nq, k, pl);
-    const float *xn = nullptr;
-    if (h->metric == KNN_METRIC_L2) {
-        if (h->ws_qn.ensure((size_t)nq * 4)) return set_err(KNN_ERR_HIP, "search: out of device memory");
-        int rc = norms_dev_impl(q_dev, nq, h->d, h->dp, (float *)h->ws_qn.p, s);
+    make_plan(h, nb, nq, k, true, pl);
+    if (level >= (int)(sizeof(h->ws_level) / sizeof(h->ws_level[0]))) return set_err(KNN_ERR_INVALID, "search: seed recursion too deep");
+    // Seeding pays when the chunks the grid needs for parallelism are short relative to k (the
+    // streaming regime: few queries, huge database); long chunks amortise their own warm-up.
+    // flags & 8 turns it off, flags & 16 forces it wherever the view is big enough (tests).
+    bool seed = nb >= std::max<int64_t>(32768, 512 * (int64_t)k) && pl.chunk_rows <= 128 * (int64_t)k;
+    if (h->flags & 16) seed = nb >= 8192 && nb >= 32 * (int64_t)k;
+    if (h->flags & 8) seed = false;
+    if (!seed) make_plan(h, nb, nq, k, level > 0, pl); // a seed sample is small: parallelism over warm-up
+    const int sstride = seed ? seed_stride(nb, k, pl.chunk_rows) : 0;
+    const int nlists = pl.nchunks + (sstride ? 1 : 0);
+    DevBuf &pbuf = h->ws_level[level];
+    if (pbuf.ensure((size_t)nq * nlists * k * 8)) return set_err(KNN_ERR_HIP, "search: out of device memory");
+    uint64_t *partial = (uint64_t *)pbuf.p;
+    int rc;
+    if (sstride) {
+        // the sample's sorted top-k lands in list slot nchunks of every query
+        rc = search_view(h, q_dev, xn, nq, k, id_base, row_mul * sstride, level + 1, partial + (size_t)pl.nchunks * k,
+                         (int64_t)nlists * k, nullptr, nullptr, s);
         if (rc) return rc;
-        xn = (const float *)h->ws_qn.p;
     }
     if (h->ws_lists.ensure((size_t)pl.grid * pl.qt * pl.cap * 8) || h->ws_gthr.ensure((size_t)pl.nqtiles * pl.qt * 4))
         return set_err(KNN_ERR_HIP, "search: out of device memory (candidate lists)");
-    // per-chunk survivor lists are unsorted: at least one merge round always follows
-    if (h->ws_partial.ensure((size_t)nq * pl.nchunks * k * 8)) return set_err(KNN_ERR_HIP, "search: out of device memory");
-    uint64_t *partial = (uint64_t *)h->ws_partial.p;
-    HIP_TRY(hipMemsetAsync(h->ws_gthr.p, 0xFF, (size_t)pl.nqtiles * pl.qt * 4, s));
+    if (sstride) {
+        const int64_t nslots = (int64_t)pl.nqtiles * pl.qt;
+        hipLaunchKernelGGL(seed_thresholds_kernel, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, s,
+                           (const uint64_t *)(partial + (size_t)pl.nchunks * k), (int64_t)nlists * k, k, nq, nslots,
+                           (uint32_t *)h->ws_gthr.p);
+        HIP_TRY(hipGetLastError());
+    } else {
+        HIP_TRY(hipMemsetAsync(h->ws_gthr.p, 0xFF, (size_t)pl.nqtiles * pl.qt * 4, s));
+    }
     ScanParams p;
     p.xb = h->xb; p.yn = h->yn; p.xq = q_dev; p.xn = xn;
-    p.nb = h->ntotal; p.nq = nq; p.dp = h->dp; p.k = k; p.cap = pl.cap;
+    p.nb = nb; p.nq = nq; p.dp = h->dp; p.k = k; p.cap = pl.cap;
     p.nqtiles = pl.nqtiles; p.nchunks = pl.nchunks; p.chunk_rows = pl.chunk_rows;
     p.lists = (uint64_t *)h->ws_lists.p; p.gthr = (uint32_t *)h->ws_gthr.p; p.partial = partial;
     p.id_base = id_base;
+    p.row_mul = row_mul;
+    p.skip_mask = sstride ? sstride - 1 : -1;
+    p.partial_lists = nlists;
     p.dbg = h->flags & 6;
-    {
+    const bool top = level == 0;
+    if (top) {
         const int slot = (int)(h->nlaunches % knn_index_s::RING);
         if (!h->ring0[slot]) {
             HIP_TRY(hipEventCreate(&h->ring0[slot]));
@@ -1198,17 +1255,33 @@ static int search_keys_impl(knn_index_s *h, const float *q_dev, int64_t nq, int 
         h->ev0 = h->ring0[slot];
         h->ev1 = h->ring1[slot];
         h->nlaunches++;
+        HIP_TRY(hipEventRecord(h->ev0, s));
     }
-    HIP_TRY(hipEventRecord(h->ev0, s));
-    int rc;
     if (pl.qt == 128) rc = launch_scan_cfg<2, 2, 2, 2>(h, p, pl, s);
     else if (pl.qt == 64) rc = launch_scan_cfg<2, 2, 2, 1>(h, p, pl, s);
     else rc = launch_scan_cfg<4, 1, 2, 1>(h, p, pl, s);
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(h->ev1, s));
-    h->last_kernel = pl.name; h->last_qt = pl.qt; h->last_dt = pl.dt; h->last_chunks = pl.nchunks; h->last_grid = pl.grid;
-    // merge rounds: per-chunk survivor lists -> sorted top-k (+ D/I)
-    return run_merge(partial, pl.nchunks, k, nq, false, h->ws_partial2, h->ws_tmp, keys_out, h->metric, D_out, I_out, s);
+    if (top) {
+        HIP_TRY(hipEventRecord(h->ev1, s));
+        h->last_kernel = pl.name; h->last_qt = pl.qt; h->last_dt = pl.dt; h->last_chunks = pl.nchunks; h->last_grid = pl.grid;
+        h->last_seed_stride = sstride;
+    }
+    // merge rounds: per-chunk survivor lists (+ the seed list) -> sorted top-k (+ D/I)
+    return run_merge(partial, nlists, k, nq, false, h->ws_partial2, h->ws_tmp, keys_out, h->metric, D_out, I_out, s, keys_stride);
+}
+
+// queries [nq][dp] already on device (padded); writes sorted keys [nq][k] and/or D/I
+static int search_keys_impl(knn_index_s *h, const float *q_dev, int64_t nq, int k, uint32_t id_base,
+                            uint64_t *keys_out, float *D_out, int64_t *I_out, hipStream_t s)
+{
+    const float *xn = nullptr;
+    if (h->metric == KNN_METRIC_L2) {
+        if (h->ws_qn.ensure((size_t)nq * 4)) return set_err(KNN_ERR_HIP, "search: out of device memory");
+        int rc = norms_dev_impl(q_dev, nq, h->d, h->dp, (float *)h->ws_qn.p, s);
+        if (rc) return rc;
+        xn = (const float *)h->ws_qn.p;
+    }
+    return search_view(h, q_dev, xn, nq, k, id_base, 1, 0, keys_out, k, D_out, I_out, s);
 }
 
 static int check_search_args(knn_index_s *h, const void *q, int64_t nq, int64_t k, const void *D, const void *I)

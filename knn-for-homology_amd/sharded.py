@@ -16,6 +16,7 @@ slices in insertion order, so global ids are ``row_offset + local row``.  A sear
 torch is used for device memory, the current stream and torch.distributed only.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -92,6 +93,8 @@ class ShardedFlatIndex:
             rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.rank, self.world = rank, world
         self.row_offset = int(row_offset)
+        # exercise the keys -> all-gather -> merge path even with one rank (tests)
+        self.force_collective = os.environ.get("KNN355_FORCE_COLLECTIVE", "0") == "1"
         self.backend = backend if backend is not None else HipShardBackend(d, metric)
 
     @property
@@ -116,7 +119,7 @@ class ShardedFlatIndex:
         """q: [nq, d] float32 tensor, identical on every rank.  Returns (D, I) tensors
         holding the global result on every rank."""
         k = int(k)
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             return self.backend.search(q, k)
         nq = q.shape[0]
         keys = self.backend.search_keys(q, k, self.row_offset)

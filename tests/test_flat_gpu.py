@@ -227,6 +227,29 @@ def test_exact_duplicates_break_ties_by_lower_id(gpu_faiss, oracle):
             assert (D[:50, :3] == 0).all()
 
 
+@pytest.mark.parametrize("metric", [0, 1])
+def test_seeded_search_matches_oracle(gpu_faiss, oracle, metric):
+    """flags=16 forces the recursive strided-sample seeding (normally reserved for the
+    streaming regime); flags=8 disables it.  Both must return the oracle's bits, also on a
+    database sorted so that every new tile beats the previous ones."""
+    rng = np.random.default_rng(31)
+    xb = rng.standard_normal((40000, 128), dtype=np.float32)
+    xq = rng.standard_normal((70, 128), dtype=np.float32)
+    Do, Io = oracle.flat_search(xb, xq, 100, metric)
+    for flags, nq in ((16, 70), (16, 20), (8, 70), (0, 20)):
+        idx = gpu_faiss.IndexFlat(128, metric)
+        idx.set_tuning(0, 0, flags)
+        idx.add(xb)
+        D, I = idx.search(xq[:nq], 100)
+        _assert_same(D, I, Do[:nq], Io[:nq])
+    xs = np.sort(rng.standard_normal((30000, 64), dtype=np.float32), axis=0)
+    q = xs[::500].copy()
+    idx = gpu_faiss.IndexFlat(64, metric)
+    idx.set_tuning(0, 0, 16)
+    idx.add(xs)
+    _assert_same(*idx.search(q, 50), *oracle.flat_search(xs, q, 50, metric))
+
+
 def test_result_independent_of_tiling(gpu_faiss):
     """The same search under every query-tile / chunk split returns identical bits."""
     rng = np.random.default_rng(8)

@@ -1,0 +1,73 @@
+"""GPU: the sharded index over RCCL.  Only one GPU is available to the test box, so the
+process group has a single rank, but the full exchange path runs (per-shard keys ->
+all_gather_into_tensor on the nccl backend -> merge kernel on a [world, nq, k] buffer), and
+a 4-shard exchange is emulated by concatenating per-shard key lists on the device."""
+import ctypes
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_single_rank_nccl_collective_path(gpu_faiss, oracle):
+    import torch
+    import torch.distributed as dist
+    from knn_for_homology_amd.sharded import ShardedFlatIndex
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        os.environ["KNN355_FORCE_COLLECTIVE"] = "1"
+        rng = np.random.default_rng(12)
+        xb = rng.standard_normal((5000, 1024), dtype=np.float32)
+        xq = rng.standard_normal((40, 1024), dtype=np.float32)
+        for metric in (0, 1):
+            idx = ShardedFlatIndex(1024, metric, row_offset=1000)
+            assert idx.force_collective
+            idx.add(xb)
+            D, I = idx.search(xq, 100)
+            Do, Io = oracle.flat_search(xb, xq, 100, metric)
+            assert np.array_equal(I, Io + 1000) and np.array_equal(D.view(np.uint32), Do.view(np.uint32))
+    finally:
+        os.environ.pop("KNN355_FORCE_COLLECTIVE", None)
+        dist.destroy_process_group()
+
+
+def test_emulated_four_shard_merge(gpu_faiss, oracle):
+    """Four shard indexes on one GPU; their key lists are stacked [4, nq, k] exactly as an
+    all-gather would deliver them and merged by knn_merge_keys_dev."""
+    import torch
+    from knn_for_homology_amd import _lib
+    from knn_for_homology_amd.sharded import HipShardBackend, shard_bounds
+    rng = np.random.default_rng(13)
+    nb, d, nq, k = 9001, 256, 70, 64
+    xb = rng.standard_normal((nb, d), dtype=np.float32)
+    xb[8000:8010] = xb[5:15]  # ties across shards -> lower global id
+    xq = np.concatenate([rng.standard_normal((nq - 5, d), dtype=np.float32), xb[5:10]])
+    dev = torch.device("cuda", 0)
+    q = torch.from_numpy(xq).to(dev)
+    for metric in (0, 1):
+        parts = []
+        backs = []
+        for r in range(4):
+            lo, hi = shard_bounds(nb, 4, r)
+            b = HipShardBackend(d, metric)
+            b.add(xb[lo:hi])
+            backs.append(b)
+            parts.append(b.search_keys(q, k, lo))
+        gathered = torch.stack(parts).contiguous()
+        D, I = backs[0].merge(gathered, 4, nq, k)
+        torch.cuda.synchronize()
+        Do, Io = oracle.flat_search(xb, xq, k, metric)
+        assert np.array_equal(I.cpu().numpy(), Io)
+        assert np.array_equal(D.cpu().numpy().view(np.uint32), Do.view(np.uint32))

@@ -112,6 +112,16 @@ def main():
     xb5 = rng.standard_normal((60000, 1024), dtype=np.float32)
     case("60k x 32q k=100", xb5, xq[:32], 100, 0)
     case("60k x 200q k=100 l2", xb5, xq[:200], 100, 1)
+    # seeded (recursive) searches: big enough that the strided sample kicks in
+    xb6 = rng.standard_normal((40000, 128), dtype=np.float32)
+    xq6 = rng.standard_normal((70, 128), dtype=np.float32)
+    case("seeded 40k d=128 k=10", xb6, xq6, 10, 0, flags=16)
+    case("seeded 40k d=128 k=100 l2", xb6, xq6, 100, 1, flags=16)
+    case("seeded 40k d=128 k=100 q32", xb6, xq6[:20], 100, 0, flags=16)
+    case("auto 40k d=128 k=10 q32", xb6, xq6[:20], 10, 0)
+    case("unseeded (flags=8) same", xb6, xq6, 100, 1, flags=8)
+    xb7 = np.sort(rng.standard_normal((30000, 64), dtype=np.float32), axis=0)  # adversarial order
+    case("sorted columns 30k d=64", xb7, xb7[::500].copy(), 50, 1, flags=16)
     print("FAILS:", fails)
     return 1 if fails else 0
 

@@ -61,6 +61,15 @@ with open(out / f"{tag}_pmc_hbm_traffic.csv", "w") as fh:
     fh.write("kernel,launches,FETCH_SIZE_KiB_raw_max,WRITE_SIZE_KiB_max,hbm_bytes_corrected\n")
     for r in rows:
         fh.write(",".join(str(x) for x in r) + "\n")
+if bench_json.exists():
+    try:
+        b = json.loads(bench_json.read_text().strip().splitlines()[-1])
+        kern = b["roofline"]["kernel"]
+        if kern in traffic:
+            traffic[kern]["algorithmic_bytes_per_launch"] = b["roofline"]["algorithmic_bytes_per_launch"]
+            traffic[kern]["workload"] = b["config"]["workload"]
+    except Exception as e:  # pragma: no cover
+        print("could not attach workload to traffic:", e)
 (out / "pmc_traffic.json").write_text(json.dumps(traffic, indent=1))
 print(open(out / f"{tag}_bench_kernel_stats.csv").read()[:1500])
 print(json.dumps(traffic, indent=1))
