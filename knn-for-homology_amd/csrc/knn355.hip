@@ -199,9 +199,10 @@ __device__ __forceinline__ int wave_sum(int x)
     return __builtin_amdgcn_readlane(x, 63);
 }
 
+typedef const __attribute__((address_space(1))) uint64_t *gptr_u64; // explicit global (not flat) loads
 struct LoadContig {
     const uint64_t *p;
-    __device__ __forceinline__ uint64_t operator()(int idx) const { return p[idx]; }
+    __device__ __forceinline__ uint64_t operator()(int idx) const { return ((gptr_u64)p)[idx]; }
 };
 // element idx of the concatenation of lists l0.. of query q inside a [list][query][k] buffer
 struct LoadListMajor {
@@ -211,9 +212,43 @@ struct LoadListMajor {
     __device__ __forceinline__ uint64_t operator()(int idx) const
     {
         const int l = idx / k, j = idx - l * k;
-        return base[((size_t)(l0 + l) * nq + q) * k + j];
+        return ((gptr_u64)base)[((size_t)(l0 + l) * nq + q) * k + j];
     }
 };
+
+// min / max over the wave and inclusive prefix sum, all with DPP row operations (no LDS
+// crossbar round trips): butterfly inside rows of 16 lanes, then row broadcasts
+#define DPP_U32(x, ctrl, rmask) ((uint32_t)__builtin_amdgcn_update_dpp((int)(x), (int)(x), ctrl, rmask, 0xF, false))
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t x)
+{
+    x = min(x, DPP_U32(x, 0xB1, 0xF));
+    x = min(x, DPP_U32(x, 0x4E, 0xF));
+    x = min(x, DPP_U32(x, 0x141, 0xF));
+    x = min(x, DPP_U32(x, 0x140, 0xF));
+    x = min(x, DPP_U32(x, 0x142, 0xA));
+    x = min(x, DPP_U32(x, 0x143, 0xC));
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x)
+{
+    x = max(x, DPP_U32(x, 0xB1, 0xF));
+    x = max(x, DPP_U32(x, 0x4E, 0xF));
+    x = max(x, DPP_U32(x, 0x141, 0xF));
+    x = max(x, DPP_U32(x, 0x140, 0xF));
+    x = max(x, DPP_U32(x, 0x142, 0xA));
+    x = max(x, DPP_U32(x, 0x143, 0xC));
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+__device__ __forceinline__ int wave_inclusive_scan(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false); // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false); // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false); // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false); // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false); // row_bcast:15 -> rows 1,3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false); // row_bcast:31 -> rows 2,3
+    return x;
+}
 
 template <int R, typename LD>
 __device__ __attribute__((noinline)) int wave_select(LD load, int n, int k, int kmax, int lane, uint32_t *thr_ord, uint64_t *dst)
@@ -224,21 +259,23 @@ __device__ __attribute__((noinline)) int wave_select(LD load, int n, int k, int 
     for (int r = 0; r < R; r++) {
         const int idx = r * 64 + lane;
         const bool valid = idx < n;
-        const uint64_t key = valid ? load(idx) : KEY_PAD;
+        uint64_t key = load(valid ? idx : n - 1); // unconditional: all R loads go out back to back
+        if (!valid) key = KEY_PAD;
         hi[r] = (uint32_t)(key >> 32);
         lo[r] = (uint32_t)key;
-        if (valid) { mn = min(mn, hi[r]); mx = max(mx, hi[r]); }
+        mn = min(mn, hi[r]);              // padding reads as the largest word
+        mx = max(mx, valid ? hi[r] : 0u);
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        mn = min(mn, (uint32_t)__shfl_xor((int)mn, off, 64));
-        mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
-    }
-    // per-lane partial counts (v_cmp + v_addc per register), one DPP reduction per probe
+    mn = wave_min_u32(mn);
+    mx = wave_max_u32(mx);
+    // per-lane partial counts, one DPP reduction per probe.  The compare/add-carry pair is
+    // spelled out: left to the scheduler, R compares are hoisted together and their R lane
+    // masks spill out of the SGPR file.
     auto count_lt = [&](uint32_t X) {
         int c = 0;
 #pragma unroll
-        for (int r = 0; r < R; r++) c += (hi[r] < X) ? 1 : 0;
+        for (int r = 0; r < R; r++)
+            asm volatile("v_cmp_lt_u32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, 0, %0, vcc" : "+v"(c) : "v"(hi[r]), "v"(X) : "vcc");
         return wave_sum(c);
     };
     uint32_t T = mx;
@@ -279,23 +316,37 @@ __device__ __attribute__((noinline)) int wave_select(LD load, int n, int k, int 
     }
     // survivors: lane-major packing (order inside a list is irrelevant).  When the cut falls
     // into the padding (fewer than k real keys) only real keys survive; the caller pads.
-    const bool tie_ok = T != 0xFFFFFFFFu;
-    int mine = 0;
+    int total;
+    if (Q == 0xFFFFFFFFu) {
+        // common case, no tie-break: keep hi < Tk
+        const uint32_t Tk = T == 0xFFFFFFFFu ? T : T + 1u;
+        int mine = 0;
 #pragma unroll
-    for (int r = 0; r < R; r++) mine += (hi[r] < Tlt || (hi[r] == T && tie_ok && lo[r] <= Q)) ? 1 : 0;
-    int incl = mine;
+        for (int r = 0; r < R; r++)
+            asm volatile("v_cmp_lt_u32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, 0, %0, vcc" : "+v"(mine) : "v"(hi[r]), "v"(Tk) : "vcc");
+        const int incl = wave_inclusive_scan(mine);
+        int pos = incl - mine;
+        total = __builtin_amdgcn_readlane(incl, 63);
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
-    }
-    int pos = incl - mine;
-    const int total = __shfl(incl, 63, 64);
+        for (int r = 0; r < R; r++) {
+            if (hi[r] < Tk) {
+                if (pos < kmax) dst[pos] = ((uint64_t)hi[r] << 32) | lo[r];
+                pos++;
+            }
+        }
+    } else {
+        int mine = 0;
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-        if (hi[r] < Tlt || (hi[r] == T && tie_ok && lo[r] <= Q)) {
-            if (pos < kmax) dst[pos] = ((uint64_t)hi[r] << 32) | lo[r];
-            pos++;
+        for (int r = 0; r < R; r++) mine += (hi[r] < Tlt || (hi[r] == T && lo[r] <= Q)) ? 1 : 0;
+        const int incl = wave_inclusive_scan(mine);
+        int pos = incl - mine;
+        total = __builtin_amdgcn_readlane(incl, 63);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if (hi[r] < Tlt || (hi[r] == T && lo[r] <= Q)) {
+                if (pos < kmax) dst[pos] = ((uint64_t)hi[r] << 32) | lo[r];
+                pos++;
+            }
         }
     }
     *thr_ord = T;
@@ -332,6 +383,7 @@ struct ScanParams {
     uint32_t id_base;
     int row_mul;       // this launch scans the strided view rows r*row_mul (r < nb)
     int skip_mask;     // >= 0: rows with (r & skip_mask) == 0 belong to the seed sample, skip them
+    int kslot;         // keys per (query, list) slot in `partial`: k + k/4
     int partial_lists; // lists per query in `partial` (nchunks, +1 when a seed list rides along)
     int dbg;           // timing experiments only: 2 = skip compaction, 4 = skip appends
 };
@@ -345,10 +397,11 @@ struct ListCtx {
     uint64_t *lists;  // [QT][cap] this workgroup's lists
     uint32_t *gthr;   // [QT] shared running thresholds of these queries
     int cap, k;
+    int kslot;        // size of this workgroup's output slot per query (k + k/4)
 
-    __device__ __forceinline__ void init(int tid, int QT)
+    __device__ __forceinline__ void init(int tid, int QT, int nthreads = 256)
     {
-        for (int i = tid; i < QT; i += 256) {
+        for (int i = tid; i < QT; i += nthreads) {
             s_thr[i] = INFINITY;
             s_cnt[i] = 0;
         }
@@ -369,18 +422,19 @@ struct ListCtx {
     }
 };
 
-// Called by all 256 threads after a tile's appends (and a barrier).  Lists that could
-// overflow on the next tile are cut back to [k, 1.25k] keys; on the last tile every list is
-// cut to exactly k and written (unsorted) to out_base + ql * out_stride.
-template <int QT>
+// Called by all threads after a tile's appends (and a barrier).  Lists that could overflow on
+// the next tile are cut back to [k, 1.25k] keys; on the last tile every list is cut to at most
+// kslot = 1.25k keys (no work at all if it already is that short) and written, unsorted and
+// padded, to out_base + ql * out_stride.  Exactness is the merge kernel's job.
+template <int QT, int NT = 256>
 __device__ __forceinline__ void lists_compact(ListCtx &L, char *smem, int tile_rows, bool last_tile, int64_t nq_valid,
                                               uint64_t *out_base, size_t out_stride, int tid)
 {
     const int lane = tid & 63, wave = tid >> 6;
     const int R = L.cap >> 6;
     if (R <= 64) {
-        // one wave per query, registers only: four queries in flight per workgroup
-        for (int ql = wave; ql < QT; ql += 4) {
+        // one wave per query, registers only: one query in flight per wave of the workgroup
+        for (int ql = wave; ql < QT; ql += NT / 64) {
             const int n = __builtin_amdgcn_readfirstlane(min(L.s_cnt[ql], L.cap));
             uint64_t *lst = L.lists + (size_t)ql * L.cap;
             uint32_t T = 0;
@@ -395,11 +449,12 @@ __device__ __forceinline__ void lists_compact(ListCtx &L, char *smem, int tile_r
             } else {
                 if (ql >= nq_valid) continue;
                 uint64_t *out = out_base + (size_t)ql * out_stride;
-                if (n > L.k) {
-                    wave_select_dispatch(R, LoadContig{lst}, n, L.k, L.k, lane, &T, out); // exactly k, unsorted
+                if (n > L.kslot) {
+                    const int cnt = wave_select_dispatch(R, LoadContig{lst}, n, L.k, L.kslot, lane, &T, out);
+                    for (int i = cnt + lane; i < L.kslot; i += 64) out[i] = KEY_PAD;
                     if (lane == 0) atomicMin(&L.gthr[ql], T);
                 } else {
-                    for (int i = lane; i < L.k; i += 64) out[i] = i < n ? lst[i] : KEY_PAD;
+                    for (int i = lane; i < L.kslot; i += 64) out[i] = i < n ? lst[i] : KEY_PAD;
                 }
             }
         }
@@ -412,15 +467,15 @@ __device__ __forceinline__ void lists_compact(ListCtx &L, char *smem, int tile_r
             if (!last_tile && n <= L.cap - tile_rows) continue;
             uint64_t *lst = L.lists + (size_t)ql * L.cap;
             const int P = next_pow2_dev(n > 0 ? n : 1);
-            for (int i = tid; i < P; i += 256) sb[i] = i < n ? lst[i] : KEY_PAD;
+            for (int i = tid; i < P; i += NT) sb[i] = i < n ? lst[i] : KEY_PAD;
             __syncthreads();
-            wg_bitonic_sort(sb, P, tid, 256);
+            wg_bitonic_sort(sb, P, tid, NT);
             const int keep = min(n, L.k);
             if (!last_tile) {
-                for (int i = tid; i < keep; i += 256) lst[i] = sb[i];
+                for (int i = tid; i < keep; i += NT) lst[i] = sb[i];
             } else if (ql < nq_valid) {
                 uint64_t *out = out_base + (size_t)ql * out_stride;
-                for (int i = tid; i < L.k; i += 256) out[i] = i < keep ? sb[i] : KEY_PAD;
+                for (int i = tid; i < L.kslot; i += NT) out[i] = i < keep ? sb[i] : KEY_PAD;
             }
             if (tid == 0) {
                 L.s_cnt[ql] = keep;
@@ -484,6 +539,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
     L.gthr = p.gthr + (size_t)qtile * QT;
     L.cap = p.cap;
     L.k = p.k;
+    L.kslot = p.kslot;
     L.init(tid, QT);
     __syncthreads();
 
@@ -612,8 +668,8 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
         // ---- compaction of lists that could overflow on the next tile ----
         const bool last_tile = row0 + DT >= c_hi;
         if ((*L.s_need || last_tile) && !(p.dbg & 2))
-            lists_compact<QT>(L, smem, DT, last_tile, p.nq - q0, p.partial + ((size_t)q0 * p.partial_lists + chunk) * p.k,
-                              (size_t)p.partial_lists * p.k, tid);
+            lists_compact<QT>(L, smem, DT, last_tile, p.nq - q0, p.partial + ((size_t)q0 * p.partial_lists + chunk) * p.kslot,
+                              (size_t)p.partial_lists * p.kslot, tid);
     }
 }
 
@@ -635,10 +691,10 @@ __global__ void seed_thresholds_kernel(const uint64_t *__restrict__ seed_keys, i
 // sorts them in LDS and emits the final D / I (or sorted keys).
 // ---------------------------------------------------------------------------
 template <bool LISTMAJOR>
-__global__ __launch_bounds__(256) void merge_select_kernel(const uint64_t *__restrict__ in, int L, int k, int64_t nq,
-                                                           int G, int Lout, uint64_t *__restrict__ out_keys,
-                                                           int64_t out_key_stride, int final_round, int metric,
-                                                           float *__restrict__ D, int64_t *__restrict__ I)
+__global__ __launch_bounds__(256) void merge_select_kernel(const uint64_t *__restrict__ in, int L, int kin, int k,
+                                                           int64_t nq, int G, int Lout, uint64_t *__restrict__ out_keys,
+                                                           int64_t out_key_stride, int out_key_fill, int final_round,
+                                                           int metric, float *__restrict__ D, int64_t *__restrict__ I)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -651,7 +707,7 @@ __global__ __launch_bounds__(256) void merge_select_kernel(const uint64_t *__res
     const int64_t q = active ? item / Lout : 0;
     const int g = active ? (int)(item % Lout) : 0;
     const int l0 = g * G, l1 = min(L, l0 + G);
-    const int n = (l1 - l0) * k;
+    const int n = (l1 - l0) * kin; // input lists hold kin keys each (kin >= k), output lists k
     uint64_t *dst = final_round ? sb : out_keys + ((size_t)q * Lout + g) * k;
     if (active) {
         int have = n;
@@ -659,13 +715,13 @@ __global__ __launch_bounds__(256) void merge_select_kernel(const uint64_t *__res
             uint32_t T;
             const int R = (n + 63) >> 6;
             if constexpr (LISTMAJOR)
-                have = wave_select_dispatch(R, LoadListMajor{in, nq, q, k, l0}, n, k, k, lane, &T, dst);
+                have = wave_select_dispatch(R, LoadListMajor{in, nq, q, kin, l0}, n, k, k, lane, &T, dst);
             else
-                have = wave_select_dispatch(R, LoadContig{in + ((size_t)q * L + l0) * k}, n, k, k, lane, &T, dst);
+                have = wave_select_dispatch(R, LoadContig{in + ((size_t)q * L + l0) * kin}, n, k, k, lane, &T, dst);
         } else {
             for (int i = lane; i < n; i += 64) {
-                if constexpr (LISTMAJOR) dst[i] = LoadListMajor{in, nq, q, k, l0}(i);
-                else dst[i] = in[((size_t)q * L + l0) * k + i];
+                if constexpr (LISTMAJOR) dst[i] = LoadListMajor{in, nq, q, kin, l0}(i);
+                else dst[i] = in[((size_t)q * L + l0) * kin + i];
             }
         }
         const int fill_to = final_round ? P : k;
@@ -687,6 +743,8 @@ __global__ __launch_bounds__(256) void merge_select_kernel(const uint64_t *__res
         }
     }
     if (!active) return;
+    if (out_keys)
+        for (int i = k + lane; i < out_key_fill; i += 64) out_keys[(size_t)q * out_key_stride + i] = KEY_PAD;
     for (int i = lane; i < k; i += 64) {
         const uint64_t key = sb[i];
         const size_t o = (size_t)q * k + i;
@@ -1088,18 +1146,19 @@ static int next_pow2_host(int n)
     return p;
 }
 
-// Runs merge rounds over `in` (L lists of k keys per query) until one list is left;
-// the last round sorts and writes keys_out (may be null) and/or D/I (may be null).
-// tmp0/tmp1: ping-pong buffers for intermediate rounds.
-static int run_merge(const uint64_t *in, int L, int k, int64_t nq, bool list_major, DevBuf &tmp0, DevBuf &tmp1,
-                     uint64_t *keys_out, int metric, float *D, int64_t *I, hipStream_t s, int64_t keys_out_stride = 0)
+// Runs merge rounds over `in` (L lists of kin >= k keys per query) until one list is left;
+// the last round sorts and writes keys_out (may be null; per-query stride keys_out_stride,
+// slots k..keys_out_fill padded) and/or D/I (may be null).  tmp0/tmp1: ping-pong buffers.
+static int run_merge(const uint64_t *in, int L, int kin, int k, int64_t nq, bool list_major, DevBuf &tmp0, DevBuf &tmp1,
+                     uint64_t *keys_out, int metric, float *D, int64_t *I, hipStream_t s, int64_t keys_out_stride = 0,
+                     int keys_out_fill = 0)
 {
     if (keys_out_stride == 0) keys_out_stride = k;
-    const int G = std::max(2, 4096 / k);
     const size_t lds_final = (size_t)4 * next_pow2_host(k) * 8;
     bool lm = list_major;
     int round = 0;
     for (;;) {
+        const int G = std::max(2, 4096 / kin);
         const int Lout = (L + G - 1) / G;
         const bool final_round = Lout == 1;
         uint64_t *out = nullptr;
@@ -1114,18 +1173,17 @@ static int run_merge(const uint64_t *in, int L, int k, int64_t nq, bool list_maj
         const unsigned grid = (unsigned)((items + 3) / 4);
         const size_t lds = final_round ? lds_final : 0;
         if (lm) {
-            if (lds > 65536) HIP_TRY(hipFuncSetAttribute((const void *)merge_select_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(merge_select_kernel<true>, dim3(grid), dim3(256), lds, s, in, L, k, nq, G, Lout, out,
-                               final_round ? keys_out_stride : (int64_t)0, final_round ? 1 : 0, metric, D, I);
+            hipLaunchKernelGGL(merge_select_kernel<true>, dim3(grid), dim3(256), lds, s, in, L, kin, k, nq, G, Lout, out,
+                               final_round ? keys_out_stride : (int64_t)0, keys_out_fill, final_round ? 1 : 0, metric, D, I);
         } else {
-            if (lds > 65536) HIP_TRY(hipFuncSetAttribute((const void *)merge_select_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(merge_select_kernel<false>, dim3(grid), dim3(256), lds, s, in, L, k, nq, G, Lout, out,
-                               final_round ? keys_out_stride : (int64_t)0, final_round ? 1 : 0, metric, D, I);
+            hipLaunchKernelGGL(merge_select_kernel<false>, dim3(grid), dim3(256), lds, s, in, L, kin, k, nq, G, Lout, out,
+                               final_round ? keys_out_stride : (int64_t)0, keys_out_fill, final_round ? 1 : 0, metric, D, I);
         }
         HIP_TRY(hipGetLastError());
         if (final_round) return 0;
         in = out;
         L = Lout;
+        kin = k;
         lm = false;
         round++;
     }
@@ -1199,8 +1257,12 @@ static int seed_stride(int64_t nb, int k, int64_t chunk_rows)
 // Exact top-k of the strided view {r * row_mul : r < ceil(ntotal / row_mul)} for queries
 // [nq][dp] on the device.  Output: sorted keys (keys_out, per-query stride keys_stride) and/or D/I.
 static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int64_t nq, int k, uint32_t id_base, int row_mul,
-                       int level, uint64_t *keys_out, int64_t keys_stride, float *D_out, int64_t *I_out, hipStream_t s)
+                       int level, uint64_t *keys_out, int64_t keys_stride, int keys_fill, float *D_out, int64_t *I_out,
+                       hipStream_t s)
 {
+    // per-chunk survivor slots: chunks stop at "at most 1.25 k" keys, the merge is exact
+    // (two slots must fit one wave_select: 2 * kslot <= 4096)
+    const int kslot = std::min(k + k / 4, 2048);
     const int64_t nb = (h->ntotal + row_mul - 1) / row_mul;
     ScanPlan pl;
     make_plan(h, nb, nq, k, true, pl);
@@ -1215,13 +1277,13 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     const int sstride = seed ? seed_stride(nb, k, pl.chunk_rows) : 0;
     const int nlists = pl.nchunks + (sstride ? 1 : 0);
     DevBuf &pbuf = h->ws_level[level];
-    if (pbuf.ensure((size_t)nq * nlists * k * 8)) return set_err(KNN_ERR_HIP, "search: out of device memory");
+    if (pbuf.ensure((size_t)nq * nlists * kslot * 8)) return set_err(KNN_ERR_HIP, "search: out of device memory");
     uint64_t *partial = (uint64_t *)pbuf.p;
     int rc;
     if (sstride) {
         // the sample's sorted top-k lands in list slot nchunks of every query
-        rc = search_view(h, q_dev, xn, nq, k, id_base, row_mul * sstride, level + 1, partial + (size_t)pl.nchunks * k,
-                         (int64_t)nlists * k, nullptr, nullptr, s);
+        rc = search_view(h, q_dev, xn, nq, k, id_base, row_mul * sstride, level + 1, partial + (size_t)pl.nchunks * kslot,
+                         (int64_t)nlists * kslot, kslot, nullptr, nullptr, s);
         if (rc) return rc;
     }
     if (h->ws_lists.ensure((size_t)pl.grid * pl.qt * pl.cap * 8) || h->ws_gthr.ensure((size_t)pl.nqtiles * pl.qt * 4))
@@ -1229,7 +1291,7 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     if (sstride) {
         const int64_t nslots = (int64_t)pl.nqtiles * pl.qt;
         hipLaunchKernelGGL(seed_thresholds_kernel, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, s,
-                           (const uint64_t *)(partial + (size_t)pl.nchunks * k), (int64_t)nlists * k, k, nq, nslots,
+                           (const uint64_t *)(partial + (size_t)pl.nchunks * kslot), (int64_t)nlists * kslot, k, nq, nslots,
                            (uint32_t *)h->ws_gthr.p);
         HIP_TRY(hipGetLastError());
     } else {
@@ -1244,6 +1306,7 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     p.row_mul = row_mul;
     p.skip_mask = sstride ? sstride - 1 : -1;
     p.partial_lists = nlists;
+    p.kslot = kslot;
     p.dbg = h->flags & 6;
     const bool top = level == 0;
     if (top) {
@@ -1267,7 +1330,8 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
         h->last_seed_stride = sstride;
     }
     // merge rounds: per-chunk survivor lists (+ the seed list) -> sorted top-k (+ D/I)
-    return run_merge(partial, nlists, k, nq, false, h->ws_partial2, h->ws_tmp, keys_out, h->metric, D_out, I_out, s, keys_stride);
+    return run_merge(partial, nlists, kslot, k, nq, false, h->ws_partial2, h->ws_tmp, keys_out, h->metric, D_out, I_out, s,
+                     keys_stride, keys_fill);
 }
 
 // queries [nq][dp] already on device (padded); writes sorted keys [nq][k] and/or D/I
@@ -1281,7 +1345,7 @@ static int search_keys_impl(knn_index_s *h, const float *q_dev, int64_t nq, int 
         if (rc) return rc;
         xn = (const float *)h->ws_qn.p;
     }
-    return search_view(h, q_dev, xn, nq, k, id_base, 1, 0, keys_out, k, D_out, I_out, s);
+    return search_view(h, q_dev, xn, nq, k, id_base, 1, 0, keys_out, k, 0, D_out, I_out, s);
 }
 
 static int check_search_args(knn_index_s *h, const void *q, int64_t nq, int64_t k, const void *D, const void *I)
@@ -1368,7 +1432,7 @@ extern "C" int knn_merge_keys_dev(int32_t device, int32_t metric, const uint64_t
     hipStream_t s = (hipStream_t)stream;
     // intermediate rounds only exist for nlists > 4096/k (more than 40 shards at k=100)
     static thread_local DevBuf t0, t1;
-    rc = run_merge(keys_dev, nlists, (int)k, nq, true, t0, t1, nullptr, metric, D_dev, I_dev, s);
+    rc = run_merge(keys_dev, nlists, (int)k, (int)k, nq, true, t0, t1, nullptr, metric, D_dev, I_dev, s);
     if (rc) return rc;
     if (!stream) HIP_TRY(hipStreamSynchronize(s));
     return 0;
