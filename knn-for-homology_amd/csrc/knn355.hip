@@ -855,6 +855,7 @@ struct DevBuf {
 
 struct knn_index_s {
     int d = 0, dp = 0, metric = 0, device = 0;
+    int num_cus = 256;
     int64_t ntotal = 0, cap_rows = 0;
     float *xb = nullptr; // [cap_rows][dp]
     float *yn = nullptr; // [cap_rows + pad]
@@ -978,6 +979,10 @@ extern "C" int knn_flat_create(int32_t d, int32_t metric, knn_handle *out)
     h->dp = round_up(d, 32);
     h->metric = metric;
     h->device = g_device;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, g_device) == hipSuccess && cus > 0) h->num_cus = cus;
+    }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         return set_err(KNN_ERR_HIP, "flat_create: stream creation failed");
@@ -1233,7 +1238,21 @@ static void make_plan(const knn_index_s *h, int64_t nb, int64_t nq, int k, bool 
     // bound the candidate-list workspace (<= 2 GiB)
     const size_t per_wg = (size_t)qt * pl.cap * 8;
     int64_t max_wgs = std::max<int64_t>(pl.nqtiles, (int64_t)((2ull << 30) / per_wg));
-    want = std::max<int64_t>(1, std::min(want, max_wgs / pl.nqtiles));
+    const int64_t want_max = std::max<int64_t>(1, std::min(ntiles, max_wgs / pl.nqtiles));
+    want = std::min(want, want_max);
+    if (h->force_chunks <= 0) {
+        // wave quantisation: workgroups run in rounds of (2 per CU); pick the chunk count near
+        // `want` that minimises rounds x tiles-per-chunk (14433 x 14433: 9 chunks = 2 full
+        // rounds of 13 tiles beat 10 chunks = 2.2 rounds of 12)
+        const int64_t slots = 2 * (int64_t)std::max(1, h->num_cus);
+        int64_t best = want, best_cost = INT64_MAX;
+        for (int64_t c = std::max<int64_t>(1, want / 2); c <= std::min(want_max, want + want / 2 + 1); c++) {
+            const int64_t rounds = (pl.nqtiles * c + slots - 1) / slots;
+            const int64_t cost = rounds * ((ntiles + c - 1) / c);
+            if (cost < best_cost || (cost == best_cost && c > best)) { best = c; best_cost = cost; }
+        }
+        want = best;
+    }
     int64_t tiles_per = (ntiles + want - 1) / want;
     pl.chunk_rows = tiles_per * pl.dt;
     pl.nchunks = (int)((nb + pl.chunk_rows - 1) / pl.chunk_rows);

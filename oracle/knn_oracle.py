@@ -41,7 +41,8 @@ _SO = _HERE / "libknn_oracle.so"
 
 def build(force: bool = False) -> Path:
     """Compile knn_oracle.c with the committed Makefile (gcc, no GPU needed)."""
-    if force or not _SO.exists() or _SO.stat().st_mtime < (_HERE / "knn_oracle.c").stat().st_mtime:
+    newest = max((_HERE / f).stat().st_mtime for f in ("knn_oracle.c", "hnsw_oracle.c", "Makefile"))
+    if force or not _SO.exists() or _SO.stat().st_mtime < newest:
         subprocess.check_call(["make", "-C", str(_HERE), "-s", "-B"])
     return _SO
 
@@ -106,6 +107,40 @@ class Oracle:
                                     ridx.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
                                     out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
         return out
+
+
+class OracleHNSW:
+    """Sequential-insertion HNSW restated on the CPU (oracle/hnsw_oracle.c): the quality
+    reference for the GPU-offloaded, batch-synchronous build."""
+
+    def __init__(self, d, M=32, metric=METRIC_L2, ef_construction=40):
+        self.lib = oracle().lib
+        L = self.lib
+        L.hnsw_orc_new.restype = ctypes.c_void_p
+        L.hnsw_orc_new.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.hnsw_orc_free.argtypes = [ctypes.c_void_p]
+        L.hnsw_orc_set_ef.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.hnsw_orc_add.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+        L.hnsw_orc_search.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        self.d = d
+        self.h = L.hnsw_orc_new(d, M, metric, ef_construction)
+
+    def add(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        self.lib.hnsw_orc_add(self.h, x.ctypes.data, x.shape[0])
+
+    def search(self, q, k, ef_search):
+        q = np.ascontiguousarray(q, np.float32)
+        self.lib.hnsw_orc_set_ef(self.h, ef_search)
+        D = np.empty((q.shape[0], k), np.float32)
+        I = np.empty((q.shape[0], k), np.int64)
+        self.lib.hnsw_orc_search(self.h, q.ctypes.data, q.shape[0], k, D.ctypes.data, I.ctypes.data)
+        return D, I
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.hnsw_orc_free(self.h)
+            self.h = None
 
 
 _ORACLE = None

@@ -147,3 +147,26 @@ def test_proteins_search_entry_point(gpu_faiss, tmp_path, capsys):
     assert np.array_equal(flat_hits, np.load(tmp_path / "full_sequences_hnsw_hits.npy"))
     with pytest.raises(ValueError):
         proteins_search.main(["prog", "ivf"], data_dir=tmp_path)
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_quality_matches_sequential_oracle(gpu_faiss, ko, metric):
+    """Batch-synchronous GPU-offloaded construction vs the sequential CPU oracle
+    (oracle/hnsw_oracle.c), same M / efConstruction / efSearch: recall must not be worse by
+    more than 2 points at any setting."""
+    n, d, nq, M = 20000, 64, 500, 16
+    x = _clustered(n, d, 300, 33)
+    gpu_faiss.normalize_L2(x)
+    flat = gpu_faiss.IndexFlat(d, metric)
+    flat.add(x)
+    _, It = flat.search(x[:nq], 10)
+    ref = ko.OracleHNSW(d, M, metric)
+    ref.add(x)
+    idx = gpu_faiss.IndexHNSWFlat(d, M, metric)
+    idx.add(x)
+    for efs in (16, 64, 256):
+        _, Iref = ref.search(x[:nq], 10, efs)
+        idx.hnsw.efSearch = efs
+        _, I = idx.search(x[:nq], 10)
+        r_ref, r_gpu = _recall(Iref, It), _recall(I, It)
+        assert r_gpu >= r_ref - 0.02, (efs, r_gpu, r_ref)
