@@ -150,6 +150,37 @@ int knn_lsh_get_codes(knn_lsh_handle h, uint8_t *out_host, int32_t bytes_per_vec
 int knn_lsh_add_codes(knn_lsh_handle h, const uint8_t *codes_host, int64_t n, int32_t bytes_per_vec);
 void knn_lsh_free(knn_lsh_handle h);
 
+/* ---- consumers of (hits, scores): SURVEY section 8(f) N4 --------------------------
+ * Host buffers in and out.  hits are int64 [nq][k] as returned by search. */
+/* pfam/proteins.py:85-122 remove_self_hit: drops the self id from each row (or the last
+ * hit when the row does not contain it: missing_out[r] = 1); outputs are [nq][k-1] */
+int knn_eval_remove_self_hit(const int64_t *hits, const float *scores, int64_t nq, int64_t k,
+                             const int64_t *self_ids, int64_t *hits_out, float *scores_out,
+                             int32_t *missing_out);
+/* seqvec_search/main.py:64-82 evaluate: lead_out[r] = hits of the query's label before the
+ * first foreign hit, tp_out[r] = hits of the query's label anywhere; is_correct_out
+ * (uint8 [nq][k], may be NULL) is the per-hit match matrix of seqvec_search/tp_cumulative.py */
+int knn_eval_labels(const int64_t *hits, int64_t nq, int64_t k, const int32_t *labels_q,
+                    const int32_t *labels_db, int64_t nb, uint8_t *is_correct_out, int32_t *lead_out,
+                    int32_t *tp_out);
+/* pfam/proteins_shared.py:139-157 compute_auc1: query r is homologous to the SORTED target
+ * rows set_members[set_offsets[r] .. set_offsets[r+1]) */
+int knn_eval_sets(const int64_t *hits, int64_t nq, int64_t k, const int64_t *set_offsets,
+                  const int64_t *set_members, int32_t *lead_out, int32_t *tp_out);
+/* cath/cath.py:76-84 compute_is_correct: out uint8 [nq][nlevels][k],
+ * out[q][l][j] = mapping[query_rows[q]][l] == mapping[hits[q][j]][l]; mapping int32 [n][nlevels] */
+int knn_eval_levels(const int64_t *hits, int64_t nq, int64_t k, const int64_t *query_rows,
+                    const int32_t *mapping, int64_t n, int32_t nlevels, uint8_t *out);
+
+/* ---- MMseqs2 prefilter database: SURVEY section 8(f) N3 ----------------------------
+ * seqvec_search/mmseqs/_write_prefilter_db.py:52-97 write_prefilter_db: data file
+ * ("<prefilter>.0") and index file ("<prefilter>.index"); queries[i] is the faiss row of
+ * query i, *_map translate faiss rows to MMseqs2 ids; clip as in the reference. */
+int knn_write_prefilter_db(const char *data_path, const char *index_path, const int64_t *hits,
+                           const float *scores, int64_t nq, int64_t k, const int64_t *queries,
+                           const int64_t *test_map, int64_t n_test, const int64_t *train_map,
+                           int64_t n_train, int32_t clip);
+
 /* ---- distances for explicit candidate lists (HNSW walk offload) --------
  * For query i (row of q_dev [nq,d]) and candidates cand[off[i] .. off[i+1]),
  * out[p] = <q,y> (IP) or max(0, |q|^2+|y|^2-2<q,y>) (L2), same arithmetic as

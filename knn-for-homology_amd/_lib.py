@@ -71,6 +71,11 @@ def _declare(L):
         "knn_lsh_get_codes": (c_int32, [H, c_void_p, c_int32]),
         "knn_lsh_add_codes": (c_int32, [H, c_void_p, c_int64, c_int32]),
         "knn_lsh_free": (None, [H]),
+        "knn_eval_remove_self_hit": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+        "knn_eval_labels": (c_int32, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+        "knn_eval_sets": (c_int32, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+        "knn_eval_levels": (c_int32, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+        "knn_write_prefilter_db": (c_int32, [c_char_p, c_char_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32]),
         "knn_scan_times": (c_int32, [H, c_void_p, c_int32]),
         "knn_flat_reserve": (c_int32, [H, c_int64]),
     }

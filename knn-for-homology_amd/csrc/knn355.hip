@@ -1620,3 +1620,4 @@ extern "C" int knn_gather_distances(knn_handle h, const float *q_host, int64_t n
 
 #include "hnsw.inc"
 #include "lsh.inc"
+#include "eval.inc"
