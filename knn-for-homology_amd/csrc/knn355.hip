@@ -39,6 +39,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef const __attribute__((address_space(1))) f32x4 *gptr4; // explicit global (not flat) loads
 
 #define KEY_PAD 0xFFFFFFFFFFFFFFFFull
 
@@ -504,9 +505,10 @@ __device__ __forceinline__ void stage_issue(const float *src, char *lds_wave_bas
 }
 
 // WM x WN waves; each wave owns TM x TN MFMA tiles of 32(db rows) x 32(queries)
-template <int WM, int WN, int TM, int TN, bool L2, bool GLDS>
+template <int WM, int WN, int TM, int TN, bool L2, int STG>
 __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 {
+    constexpr bool GLDS = STG == 0;
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int DT = WM * TM * 32;        // database rows per tile
     constexpr int QT = WN * TN * 32;        // queries per workgroup
@@ -589,23 +591,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
                 tsrc[n] = srcp[n];
             }
         }
-        f32x4 sreg[NI];
-        // prologue: stage K step 0 into buffer 0
-#pragma unroll
-        for (int n = 0; n < NI; n++) {
-            stage_issue<GLDS>(tsrc[n], stage0 + lds_off[n], lane, sreg[n]);
-            if constexpr (!GLDS) *(f32x4 *)(stage0 + lds_off[n] + lane * 16) = sreg[n];
-        }
-
-        for (int kt = 0; kt < KT; kt++) {
-            char *cur = (kt & 1) ? stage1 : stage0;
-            char *nxt = (kt & 1) ? stage0 : stage1;
-            __syncthreads(); // stage kt landed (vmcnt(0) + barrier); buffer nxt is free
-            if (kt + 1 < KT) {
-#pragma unroll
-                for (int n = 0; n < NI; n++)
-                    stage_issue<GLDS>(tsrc[n] + (kt + 1) * 32, nxt + lds_off[n], lane, sreg[n]);
-            }
+        auto compute = [&](const char *cur) {
             const char *A = cur;
             const char *B = cur + DT * 128;
 #pragma unroll
@@ -618,6 +604,13 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 #pragma unroll
                 for (int b = 0; b < TN; b++)
                     bf[b] = *(const f32x4 *)(B + ((wn * TN + b) * 32 + li) * 128 + slot);
+                if (p.dbg & 128) { // timing experiment: fragments read, no MFMA
+#pragma unroll
+                    for (int a = 0; a < TM; a++) asm volatile("" ::"v"(af[a]));
+#pragma unroll
+                    for (int b = 0; b < TN; b++) asm volatile("" ::"v"(bf[b]));
+                    continue;
+                }
 #pragma unroll
                 for (int m = 0; m < 4; m++)
 #pragma unroll
@@ -626,10 +619,69 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
                         for (int b = 0; b < TN; b++)
                             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][m], bf[b][m], acc[a][b], 0, 0, 0);
             }
-            if constexpr (!GLDS) {
+        };
+        if constexpr (STG == 2) {
+            // Register ring: stage s+1 and s+2 are in flight in VGPRs while stage s is multiplied
+            // from LDS -- twice the bytes in flight of the double-buffered LDS-DMA form without
+            // more LDS.  ra holds odd stages, rb even ones (>= 2); plain loads, so the compiler's
+            // counted vmcnt leaves the younger register set in flight and __syncthreads() is a
+            // bare s_barrier.
+            f32x4 ra[NI], rb[NI];
+#pragma unroll
+            for (int n = 0; n < NI; n++) ra[n] = *(gptr4)(tsrc[n]);
+#pragma unroll
+            for (int n = 0; n < NI; n++) *(f32x4 *)(stage0 + lds_off[n] + lane * 16) = ra[n];
+            // loads are issued unconditionally (stage index clamped): a load that only happens
+            // on some paths makes the compiler fall back to the most conservative vmcnt
+            {
+                const int s1 = min(1, KT - 1) * 32, s2 = min(2, KT - 1) * 32;
+#pragma unroll
+                for (int n = 0; n < NI; n++) ra[n] = *(gptr4)(tsrc[n] + s1);
+#pragma unroll
+                for (int n = 0; n < NI; n++) rb[n] = *(gptr4)(tsrc[n] + s2);
+            }
+            auto step = [&](int sidx, f32x4(&rs)[NI]) {
+                char *cur = (sidx & 1) ? stage1 : stage0;
+                char *nxt = (sidx & 1) ? stage0 : stage1;
+                __syncthreads(); // stage sidx is in LDS for everyone; nxt is no longer being read
+                // branch-free body (the write after the last stage lands in a buffer nobody reads)
+#pragma unroll
+                for (int n = 0; n < NI; n++) *(f32x4 *)(nxt + lds_off[n] + lane * 16) = rs[n];
+                {
+                    const int sn = min(sidx + 3, KT - 1) * 32;
+#pragma unroll
+                    for (int n = 0; n < NI; n++) rs[n] = *(gptr4)(tsrc[n] + sn);
+                }
+                compute(cur);
+            };
+            for (int kt = 0; kt + 1 < KT; kt += 2) {
+                step(kt, ra);
+                step(kt + 1, rb);
+            }
+            if (KT & 1) step(KT - 1, ra);
+        } else {
+            f32x4 sreg[NI];
+            // prologue: stage K step 0 into buffer 0
+#pragma unroll
+            for (int n = 0; n < NI; n++) {
+                stage_issue<GLDS>(tsrc[n], stage0 + lds_off[n], lane, sreg[n]);
+                if constexpr (!GLDS) *(f32x4 *)(stage0 + lds_off[n] + lane * 16) = sreg[n];
+            }
+            for (int kt = 0; kt < KT; kt++) {
+                char *cur = (kt & 1) ? stage1 : stage0;
+                char *nxt = (kt & 1) ? stage0 : stage1;
+                __syncthreads(); // stage kt landed (vmcnt(0) + barrier); buffer nxt is free
                 if (kt + 1 < KT) {
 #pragma unroll
-                    for (int n = 0; n < NI; n++) *(f32x4 *)(nxt + lds_off[n] + lane * 16) = sreg[n];
+                    for (int n = 0; n < NI; n++)
+                        stage_issue<GLDS>(tsrc[n] + (kt + 1) * 32, nxt + lds_off[n], lane, sreg[n]);
+                }
+                compute(cur);
+                if constexpr (!GLDS) {
+                    if (kt + 1 < KT) {
+#pragma unroll
+                        for (int n = 0; n < NI; n++) *(f32x4 *)(nxt + lds_off[n] + lane * 16) = sreg[n];
+                    }
                 }
             }
         }
@@ -1205,13 +1257,15 @@ struct ScanPlan {
 template <int WM, int WN, int TM, int TN>
 static int launch_scan_cfg(const knn_index_s *h, const ScanParams &p, const ScanPlan &plan, hipStream_t s)
 {
-    const bool glds = !(h->flags & 1);
+    // staging variant: 0 = LDS-DMA double buffer, 1 = register staged (flags & 1, test build),
+    // 2 = register ring two stages ahead (flags & 64)
+    const int stg = (h->flags & 64) ? 2 : ((h->flags & 1) ? 1 : 0);
     const bool l2 = h->metric == KNN_METRIC_L2;
     void (*kern)(ScanParams) = nullptr;
     if (l2)
-        kern = glds ? flat_scan_kernel<WM, WN, TM, TN, true, true> : flat_scan_kernel<WM, WN, TM, TN, true, false>;
+        kern = stg == 0 ? flat_scan_kernel<WM, WN, TM, TN, true, 0> : (stg == 1 ? flat_scan_kernel<WM, WN, TM, TN, true, 1> : flat_scan_kernel<WM, WN, TM, TN, true, 2>);
     else
-        kern = glds ? flat_scan_kernel<WM, WN, TM, TN, false, true> : flat_scan_kernel<WM, WN, TM, TN, false, false>;
+        kern = stg == 0 ? flat_scan_kernel<WM, WN, TM, TN, false, 0> : (stg == 1 ? flat_scan_kernel<WM, WN, TM, TN, false, 1> : flat_scan_kernel<WM, WN, TM, TN, false, 2>);
     HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds));
     hipLaunchKernelGGL(kern, dim3(plan.grid), dim3(256), plan.lds, s, p);
     HIP_TRY(hipGetLastError());
@@ -1286,10 +1340,11 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     ScanPlan pl;
     make_plan(h, nb, nq, k, true, pl);
     if (level >= (int)(sizeof(h->ws_level) / sizeof(h->ws_level[0]))) return set_err(KNN_ERR_INVALID, "search: seed recursion too deep");
-    // Seeding pays when the chunks the grid needs for parallelism are short relative to k (the
-    // streaming regime: few queries, huge database); long chunks amortise their own warm-up.
-    // flags & 8 turns it off, flags & 16 forces it wherever the view is big enough (tests).
-    bool seed = nb >= std::max<int64_t>(32768, 512 * (int64_t)k) && pl.chunk_rows <= 128 * (int64_t)k;
+    // Seeding pays when the sample that gives every chunk a tight threshold (about two chunks'
+    // worth of rows, at least 64 k) is a small fraction of the view: the streaming regime (few
+    // queries, huge database, hundreds of chunks).  Batch searches have few long chunks that
+    // amortise their own warm-up.  flags & 8 turns it off, flags & 16 forces it (tests).
+    bool seed = nb >= 512 * (int64_t)k && std::max<int64_t>(2 * pl.chunk_rows, 64 * (int64_t)k) <= nb / 32;
     if (h->flags & 16) seed = nb >= 8192 && nb >= 32 * (int64_t)k;
     if (h->flags & 8) seed = false;
     if (!seed) make_plan(h, nb, nq, k, level > 0, pl); // a seed sample is small: parallelism over warm-up
@@ -1326,7 +1381,7 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     p.skip_mask = sstride ? sstride - 1 : -1;
     p.partial_lists = nlists;
     p.kslot = kslot;
-    p.dbg = h->flags & 6;
+    p.dbg = h->flags & (6 | 128 | 256);
     const bool top = level == 0;
     if (top) {
         const int slot = (int)(h->nlaunches % knn_index_s::RING);
