@@ -25,6 +25,8 @@ if bench_json.exists():
 
 
 def short(name):
+    if "flat_scan_kernel" in name and name.rstrip(">(ScanParams) ").endswith("true"):
+        return "flat_scan_sample_pass"
     if "flat_scan_kernel<4, 1, 2, 1" in name:
         return "flat_scan_q32_d256"
     if "flat_scan_kernel<2, 2, 2, 1" in name:
