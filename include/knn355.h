@@ -51,6 +51,9 @@ const char *knn_last_error(void);
 const char *knn_version(void);
 /* number of visible HIP devices (0 if none); never initialises a context */
 int knn_device_count(void);
+/* freed index storage and scratch buffers are kept in a per-device pool (<= 8 GiB) for the
+ * next index; knn_trim() returns them to the driver and reports the bytes released */
+int64_t knn_trim(void);
 /* selects the device used by indexes created afterwards by this thread and
  * lazily creates its context (fork safe: nothing happens at load time;
  * cath/compare_seqvec_layer.py:58-64 calls search from forked workers) */

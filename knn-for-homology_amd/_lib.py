@@ -31,6 +31,7 @@ def _declare(L):
         "knn_version": (c_char_p, []),
         "knn_device_count": (c_int32, []),
         "knn_init": (c_int32, [c_int32]),
+        "knn_trim": (c_int64, []),
         "knn_normalize_l2": (c_int32, [c_void_p, c_int64, c_int32]),
         "knn_normalize_l2_dev": (c_int32, [c_void_p, c_int64, c_int32, c_void_p]),
         "knn_flat_create": (c_int32, [c_int32, c_int32, POINTER(H)]),

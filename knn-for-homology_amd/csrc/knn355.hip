@@ -883,18 +883,81 @@ static int set_err(int code, const std::string &msg)
             return set_err(KNN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
     } while (0)
 
+// Device scratch buffers are recycled through a small per-device pool: the reference's scripts
+// build a fresh index per embedding file (cath/search.py:20-24), and hipMalloc/hipFree of the
+// gigabyte-sized candidate-list workspace would otherwise dominate their end-to-end time.
+struct DevPool {
+    struct Item { void *p; size_t bytes; int device; };
+    std::mutex mu;
+    std::vector<Item> items;
+    size_t total = 0;
+    static constexpr size_t kMaxBytes = 8ull << 30;
+    void *take(size_t need, int device, size_t *got)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        int best = -1;
+        for (int i = 0; i < (int)items.size(); i++)
+            if (items[i].device == device && items[i].bytes >= need && items[i].bytes <= need * 4 + (1u << 20) &&
+                (best < 0 || items[i].bytes < items[best].bytes))
+                best = i;
+        if (best < 0) return nullptr;
+        void *p = items[best].p;
+        *got = items[best].bytes;
+        total -= items[best].bytes;
+        items.erase(items.begin() + best);
+        return p;
+    }
+    void give(void *p, size_t bytes, int device)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (total + bytes <= kMaxBytes && items.size() < 64) {
+                items.push_back({p, bytes, device});
+                total += bytes;
+                return;
+            }
+        }
+        (void)hipFree(p);
+    }
+};
+static DevPool g_pool;
+
+extern "C" int64_t knn_trim(void)
+{
+    std::vector<DevPool::Item> items;
+    {
+        std::lock_guard<std::mutex> lk(g_pool.mu);
+        items.swap(g_pool.items);
+        g_pool.total = 0;
+    }
+    int64_t freed = 0;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (auto &it : items) {
+        if (hipSetDevice(it.device) == hipSuccess && hipFree(it.p) == hipSuccess) freed += (int64_t)it.bytes;
+    }
+    (void)hipSetDevice(cur);
+    return freed;
+}
+
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
+    int device = 0;
     int ensure(size_t need)
     {
         if (need <= bytes) return 0;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        bytes = 0;
+        release();
+        (void)hipGetDevice(&device);
+        size_t got = 0;
+        if (void *q = g_pool.take(need, device, &got)) {
+            p = q;
+            bytes = got;
+            return 0;
+        }
         size_t want = need + need / 4;
         if (hipMalloc(&p, want) != hipSuccess) {
-            if (hipMalloc(&p, need) != hipSuccess) return -1;
+            if (hipMalloc(&p, need) != hipSuccess) { p = nullptr; return -1; }
             want = need;
         }
         bytes = want;
@@ -902,7 +965,7 @@ struct DevBuf {
     }
     void release()
     {
-        if (p) (void)hipFree(p);
+        if (p) g_pool.give(p, bytes, device);
         p = nullptr;
         bytes = 0;
     }
@@ -914,6 +977,7 @@ struct knn_index_s {
     int64_t ntotal = 0, cap_rows = 0;
     float *xb = nullptr; // [cap_rows][dp]
     float *yn = nullptr; // [cap_rows + pad]
+    size_t xb_bytes = 0, yn_bytes = 0; // allocation sizes (may exceed the row capacity: pooled)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr; // the pair of the most recent scan launch
     static const int RING = 64;
@@ -1046,10 +1110,20 @@ extern "C" int knn_flat_create(int32_t d, int32_t metric, knn_handle *out)
     return 0;
 }
 
+// database storage goes through the same pool as the scratch buffers
+static void *pool_alloc(size_t bytes, int device, size_t *got)
+{
+    if (void *q = g_pool.take(bytes, device, got)) return q;
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    *got = bytes;
+    return p;
+}
+
 static void free_index_buffers(knn_index_s *h)
 {
-    if (h->xb) (void)hipFree(h->xb);
-    if (h->yn) (void)hipFree(h->yn);
+    if (h->xb) g_pool.give(h->xb, h->xb_bytes, h->device);
+    if (h->yn) g_pool.give(h->yn, h->yn_bytes, h->device);
     h->xb = nullptr;
     h->yn = nullptr;
     h->ntotal = 0;
@@ -1093,14 +1167,17 @@ static int grow_index(knn_index_s *h, int64_t need_rows)
     if (need_rows <= h->cap_rows) return 0;
     int64_t new_cap = std::max<int64_t>(need_rows, h->cap_rows + h->cap_rows / 2);
     if (h->cap_rows == 0) new_cap = need_rows; // first add: exact fit (the reference adds once)
-    float *nxb = nullptr, *nyn = nullptr;
     size_t row_bytes = (size_t)h->dp * 4;
-    if (hipMalloc((void **)&nxb, (size_t)new_cap * row_bytes) != hipSuccess) {
+    size_t xb_got = 0, yn_got = 0;
+    float *nxb = (float *)pool_alloc((size_t)new_cap * row_bytes, h->device, &xb_got);
+    if (!nxb) {
         new_cap = need_rows;
-        HIP_TRY(hipMalloc((void **)&nxb, (size_t)new_cap * row_bytes));
+        nxb = (float *)pool_alloc((size_t)new_cap * row_bytes, h->device, &xb_got);
+        if (!nxb) return set_err(KNN_ERR_HIP, "add: out of device memory");
     }
-    if (hipMalloc((void **)&nyn, ((size_t)new_cap + 64) * 4) != hipSuccess) {
-        (void)hipFree(nxb);
+    float *nyn = (float *)pool_alloc(((size_t)new_cap + 64) * 4, h->device, &yn_got);
+    if (!nyn) {
+        g_pool.give(nxb, xb_got, h->device);
         return set_err(KNN_ERR_HIP, "add: out of device memory");
     }
     if (h->ntotal > 0) {
@@ -1108,10 +1185,12 @@ static int grow_index(knn_index_s *h, int64_t need_rows)
         HIP_TRY(hipMemcpyAsync(nyn, h->yn, (size_t)h->ntotal * 4, hipMemcpyDeviceToDevice, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
-    if (h->xb) (void)hipFree(h->xb);
-    if (h->yn) (void)hipFree(h->yn);
+    if (h->xb) g_pool.give(h->xb, h->xb_bytes, h->device);
+    if (h->yn) g_pool.give(h->yn, h->yn_bytes, h->device);
     h->xb = nxb;
     h->yn = nyn;
+    h->xb_bytes = xb_got;
+    h->yn_bytes = yn_got;
     h->cap_rows = new_cap;
     return 0;
 }
@@ -1596,11 +1675,13 @@ extern "C" int knn_flat_reserve(knn_handle h, int64_t nrows)
     HIP_TRY(hipSetDevice(h->device));
     if (nrows <= h->cap_rows) return 0;
     // exact-size allocation (grow_index over-allocates only when it has to guess)
-    float *nxb = nullptr, *nyn = nullptr;
     const size_t row_bytes = (size_t)h->dp * 4;
-    HIP_TRY(hipMalloc((void **)&nxb, (size_t)nrows * row_bytes));
-    if (hipMalloc((void **)&nyn, ((size_t)nrows + 64) * 4) != hipSuccess) {
-        (void)hipFree(nxb);
+    size_t xb_got = 0, yn_got = 0;
+    float *nxb = (float *)pool_alloc((size_t)nrows * row_bytes, h->device, &xb_got);
+    if (!nxb) return set_err(KNN_ERR_HIP, "reserve: out of device memory");
+    float *nyn = (float *)pool_alloc(((size_t)nrows + 64) * 4, h->device, &yn_got);
+    if (!nyn) {
+        g_pool.give(nxb, xb_got, h->device);
         return set_err(KNN_ERR_HIP, "reserve: out of device memory");
     }
     if (h->ntotal > 0) {
@@ -1608,10 +1689,12 @@ extern "C" int knn_flat_reserve(knn_handle h, int64_t nrows)
         HIP_TRY(hipMemcpyAsync(nyn, h->yn, (size_t)h->ntotal * 4, hipMemcpyDeviceToDevice, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
-    if (h->xb) (void)hipFree(h->xb);
-    if (h->yn) (void)hipFree(h->yn);
+    if (h->xb) g_pool.give(h->xb, h->xb_bytes, h->device);
+    if (h->yn) g_pool.give(h->yn, h->yn_bytes, h->device);
     h->xb = nxb;
     h->yn = nyn;
+    h->xb_bytes = xb_got;
+    h->yn_bytes = yn_got;
     h->cap_rows = nrows;
     return 0;
 }
