@@ -253,20 +253,24 @@ __device__ __forceinline__ int wave_inclusive_scan(int x)
 }
 
 template <int R, typename LD>
-__device__ __attribute__((noinline)) int wave_select(LD load, int n, int k, int kmax, int lane, uint32_t *thr_ord, uint64_t *dst)
+__device__ __attribute__((noinline)) int wave_select(LD load, int n, int k, int kmax, int lane, uint32_t *thr_ord, uint64_t *dst,
+                                                     uint32_t *hist)
 {
+    static_assert(R <= 64, "at most 4096 keys per wave");
     uint32_t hi[R], lo[R];
     uint32_t mn = 0xFFFFFFFFu, mx = 0u;
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int idx = r * 64 + lane;
         const bool valid = idx < n;
-        uint64_t key = load(valid ? idx : n - 1); // unconditional: all R loads go out back to back
+        uint64_t key = load(valid ? idx : n - 1); // unconditional: loads go out back to back
         if (!valid) key = KEY_PAD;
         hi[r] = (uint32_t)(key >> 32);
         lo[r] = (uint32_t)key;
         mn = min(mn, hi[r]);              // padding reads as the largest word
         mx = max(mx, valid ? hi[r] : 0u);
+        // groups of 16 loads: keeps the address registers of at most 16 loads alive at a time
+        if ((r & 15) == 15) __builtin_amdgcn_sched_barrier(0);
     }
     mn = wave_min_u32(mn);
     mx = wave_max_u32(mx);
@@ -282,7 +286,51 @@ __device__ __attribute__((noinline)) int wave_select(LD load, int n, int k, int 
     };
     uint32_t T = mx;
     int cnt = n;
-    if (mn != mx) {
+    if (mn != mx && hist) {
+        // Experiment (flags & 256): byte-wise radix select through a 256-bin LDS histogram private
+        // to this wave: at most four passes (leading bytes shared by all keys are skipped), each
+        // pass one LDS atomic per key still matching the prefix, one ds_read_b128 + DPP scan over
+        // the bins.  Measured: no faster than the bitwise search in the scan kernels and slower
+        // in the merge (scores crowd into a few bins, the atomics serialise).
+        int shift = 24;
+        while (shift > 0 && (mn >> shift) == (mx >> shift)) shift -= 8;
+        uint32_t prefix = shift == 24 ? 0u : (mx >> (shift + 8)) << (shift + 8);
+        int c_below = 0; // keys strictly below the current prefix range
+        for (;;) {
+            *(uint4 *)(hist + 4 * lane) = make_uint4(0u, 0u, 0u, 0u);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const uint32_t pmask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8)); // bits already decided
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if (((hi[r] ^ prefix) & pmask) == 0u) atomicAdd(&hist[(hi[r] >> shift) & 255u], 1u);
+                if ((r & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const uint4 h4 = *(const uint4 *)(hist + 4 * lane);
+            const int s4 = (int)(h4.x + h4.y + h4.z + h4.w);
+            const int incl = wave_inclusive_scan(s4);
+            const int need = k - c_below;
+            const uint64_t m = __ballot(incl >= need);
+            const int Ls = m ? __builtin_ctzll(m) : 63;
+            int cum = __builtin_amdgcn_readlane(incl - s4, Ls);
+            const int b0 = __builtin_amdgcn_readlane((int)h4.x, Ls), b1 = __builtin_amdgcn_readlane((int)h4.y, Ls);
+            const int b2 = __builtin_amdgcn_readlane((int)h4.z, Ls), b3 = __builtin_amdgcn_readlane((int)h4.w, Ls);
+            int bin = 4 * Ls, cb = b0;
+            if (cum + b0 < need) { cum += b0; bin++; cb = b1;
+                if (cum + b1 < need) { cum += b1; bin++; cb = b2;
+                    if (cum + b2 < need) { cum += b2; bin++; cb = b3; } } }
+            const int c_le = c_below + cum + cb; // keys whose word is <= the top of this bin
+            const uint32_t top = prefix | ((uint32_t)bin << shift) | ((shift ? (1u << shift) : 1u) - 1u);
+            if (c_le <= kmax || shift == 0) {
+                T = top; // shift == 0: the exact k-th smallest word
+                cnt = c_le;
+                break;
+            }
+            c_below += cum;
+            prefix |= (uint32_t)bin << shift;
+            shift -= 8;
+        }
+    } else if (mn != mx) {
         const int b0 = 31 - __clz((int)(mn ^ mx));
         uint32_t P = (b0 == 31) ? 0u : (mx & ~((2u << b0) - 1u));
         bool done = false;
@@ -305,14 +353,15 @@ __device__ __attribute__((noinline)) int wave_select(LD load, int n, int k, int 
     uint32_t Q = 0xFFFFFFFFu;
     const uint32_t Tlt = T; // keys with hi < Tlt are kept unconditionally, hi == T only with lo <= Q
     if (cnt > kmax && T != 0xFFFFFFFFu) { // (padding keys are interchangeable: the bounded store below trims them)
-        // more keys tie at T than may be kept: lowest ids win
+        // more keys tie at T than may be kept: lowest ids win (rare: exact duplicates)
         const int need = k - count_lt(T);
         Q = 0u;
         for (int bit = 31; bit >= 0; --bit) {
             const uint32_t Qt = Q | (1u << bit);
             int c = 0;
 #pragma unroll
-            for (int r = 0; r < R; r++) c += (hi[r] == T && lo[r] < Qt) ? 1 : 0;
+            for (int r = 0; r < R; r++)
+                c += (hi[r] == T && lo[r] < Qt) ? 1 : 0;
             if (wave_sum(c) <= need - 1) Q = Qt;
         }
     }
@@ -355,14 +404,25 @@ __device__ __attribute__((noinline)) int wave_select(LD load, int n, int k, int 
     return min(total, kmax);
 }
 
+// hist: 256 x uint32 of LDS private to the calling wave (radix select), or nullptr (binary search)
 template <typename LD>
 __device__ __forceinline__ int wave_select_dispatch(int R, LD load, int n, int k, int kmax, int lane,
-                                                    uint32_t *thr_ord, uint64_t *dst)
+                                                    uint32_t *thr_ord, uint64_t *dst, uint32_t *hist)
 {
-    if (R <= 8) return wave_select<8, LD>(load, n, k, kmax, lane, thr_ord, dst);
-    if (R <= 16) return wave_select<16, LD>(load, n, k, kmax, lane, thr_ord, dst);
-    if (R <= 32) return wave_select<32, LD>(load, n, k, kmax, lane, thr_ord, dst);
-    return wave_select<64, LD>(load, n, k, kmax, lane, thr_ord, dst);
+    if (R <= 8) return wave_select<8, LD>(load, n, k, kmax, lane, thr_ord, dst, hist);
+    if (R <= 16) return wave_select<16, LD>(load, n, k, kmax, lane, thr_ord, dst, hist);
+    return wave_select<32, LD>(load, n, k, kmax, lane, thr_ord, dst, hist); // callers guarantee n <= 2048
+}
+
+// The merge kernel may also use 64 keys per lane (4096 keys): it is its own kernel, so the
+// 250 registers of that variant do not cost the scan kernels their second wave per SIMD
+// (a non-inlined callee's registers count for every kernel that can reach it).
+template <typename LD>
+__device__ __forceinline__ int wave_select_dispatch64(int R, LD load, int n, int k, int kmax, int lane,
+                                                      uint32_t *thr_ord, uint64_t *dst, uint32_t *hist)
+{
+    if (R <= 32) return wave_select_dispatch(R, load, n, k, kmax, lane, thr_ord, dst, hist);
+    return wave_select<64, LD>(load, n, k, kmax, lane, thr_ord, dst, hist);
 }
 
 // ---------------------------------------------------------------------------
@@ -400,6 +460,7 @@ struct ListCtx {
     uint32_t *gthr;   // [QT] shared running thresholds of these queries
     int cap, k;
     int kslot;        // size of this workgroup's output slot per query (k + k/4)
+    int use_hist;     // radix select through an LDS histogram (0: bitwise binary search)
 
     __device__ __forceinline__ void init(int tid, int QT, int nthreads = 256)
     {
@@ -434,7 +495,8 @@ __device__ __forceinline__ void lists_compact(ListCtx &L, char *smem, int tile_r
 {
     const int lane = tid & 63, wave = tid >> 6;
     const int R = L.cap >> 6;
-    if (R <= 64) {
+    uint32_t *hist = L.use_hist ? (uint32_t *)smem + 256 * wave : nullptr; // staging LDS is idle between tiles
+    if (R <= 32) {
         // one wave per query, registers only: one query in flight per wave of the workgroup
         for (int ql = wave; ql < QT; ql += NT / 64) {
             const int n = __builtin_amdgcn_readfirstlane(min(L.s_cnt[ql], L.cap));
@@ -442,7 +504,7 @@ __device__ __forceinline__ void lists_compact(ListCtx &L, char *smem, int tile_r
             uint32_t T = 0;
             if (!last_tile) {
                 if (n <= L.cap - tile_rows) continue;
-                const int cnt = wave_select_dispatch(R, LoadContig{lst}, n, L.k, L.k + (L.k >> 2), lane, &T, lst);
+                const int cnt = wave_select_dispatch(R, LoadContig{lst}, n, L.k, L.k + (L.k >> 2), lane, &T, lst, hist);
                 if (lane == 0) {
                     L.s_cnt[ql] = cnt;
                     L.s_thr[ql] = ord2f(T);
@@ -452,7 +514,7 @@ __device__ __forceinline__ void lists_compact(ListCtx &L, char *smem, int tile_r
                 if (ql >= nq_valid) continue;
                 uint64_t *out = out_base + (size_t)ql * out_stride;
                 if (n > L.kslot) {
-                    const int cnt = wave_select_dispatch(R, LoadContig{lst}, n, L.k, L.kslot, lane, &T, out);
+                    const int cnt = wave_select_dispatch(R, LoadContig{lst}, n, L.k, L.kslot, lane, &T, out, hist);
                     for (int i = cnt + lane; i < L.kslot; i += 64) out[i] = KEY_PAD;
                     if (lane == 0) atomicMin(&L.gthr[ql], T);
                 } else {
@@ -462,7 +524,7 @@ __device__ __forceinline__ void lists_compact(ListCtx &L, char *smem, int tile_r
         }
         __syncthreads();
     } else {
-        // k close to KNN_MAX_K: lists too long for registers, whole-workgroup LDS sort
+        // k > 1536: lists too long for the register select, whole-workgroup LDS sort
         uint64_t *sb = (uint64_t *)smem;
         for (int ql = 0; ql < QT; ql++) {
             const int n = min(L.s_cnt[ql], L.cap);
@@ -545,6 +607,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
     L.cap = p.cap;
     L.k = p.k;
     L.kslot = p.kslot;
+    L.use_hist = (p.dbg & 256) != 0; // experiment: LDS-histogram radix select instead of the bitwise search
     L.init(tid, QT);
     __syncthreads();
 
@@ -755,7 +818,8 @@ __global__ __launch_bounds__(256) void merge_select_kernel(const uint64_t *__res
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int P = 64;
     while (P < k) P <<= 1;
-    uint64_t *sb = (uint64_t *)smem + (size_t)wave * P;
+    uint32_t *hist = nullptr; // bitwise search (the LDS-histogram radix variant measured slower here)
+    uint64_t *sb = (uint64_t *)smem + (size_t)wave * P; // final round only
     const int64_t item = (int64_t)blockIdx.x * 4 + wave;
     const int64_t nitems = nq * Lout;
     const bool active = item < nitems;
@@ -770,9 +834,9 @@ __global__ __launch_bounds__(256) void merge_select_kernel(const uint64_t *__res
             uint32_t T;
             const int R = (n + 63) >> 6;
             if constexpr (LISTMAJOR)
-                have = wave_select_dispatch(R, LoadListMajor{in, nq, q, kin, l0}, n, k, k, lane, &T, dst);
+                have = wave_select_dispatch64(R, LoadListMajor{in, nq, q, kin, l0}, n, k, k, lane, &T, dst, hist);
             else
-                have = wave_select_dispatch(R, LoadContig{in + ((size_t)q * L + l0) * kin}, n, k, k, lane, &T, dst);
+                have = wave_select_dispatch64(R, LoadContig{in + ((size_t)q * L + l0) * kin}, n, k, k, lane, &T, dst, hist);
         } else {
             for (int i = lane; i < n; i += 64) {
                 if constexpr (LISTMAJOR) dst[i] = LoadListMajor{in, nq, q, kin, l0}(i);
@@ -805,6 +869,55 @@ __global__ __launch_bounds__(256) void merge_select_kernel(const uint64_t *__res
         const size_t o = (size_t)q * k + i;
         if (out_keys) out_keys[(size_t)q * out_key_stride + i] = key;
         if (D) {
+            if (key == KEY_PAD) {
+                D[o] = metric == KNN_METRIC_INNER_PRODUCT ? -FLT_MAX : FLT_MAX;
+                I[o] = -1;
+            } else {
+                const float v = ord2f((uint32_t)(key >> 32));
+                D[o] = metric == KNN_METRIC_INNER_PRODUCT ? -v : v;
+                I[o] = (int64_t)(uint32_t)key;
+            }
+        }
+    }
+}
+
+// k > 1536 (beyond the reference's k = 1000): one workgroup sorts the union of up to G lists
+// (<= 8192 keys) of one query in LDS.  Same interface as merge_select_kernel.
+template <bool LISTMAJOR>
+__global__ __launch_bounds__(256) void merge_sort_kernel(const uint64_t *__restrict__ in, int L, int kin, int k, int64_t nq,
+                                                         int G, int Lout, uint64_t *__restrict__ out_keys,
+                                                         int64_t out_key_stride, int out_key_fill, int final_round,
+                                                         int metric, float *__restrict__ D, int64_t *__restrict__ I)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t *sb = (uint64_t *)smem;
+    const int tid = threadIdx.x;
+    const int64_t q = blockIdx.x / Lout;
+    const int g = blockIdx.x % Lout;
+    const int l0 = g * G, l1 = min(L, l0 + G);
+    const int n = (l1 - l0) * kin;
+    int P = 64;
+    while (P < n) P <<= 1;
+    for (int i = tid; i < P; i += 256) {
+        uint64_t v = KEY_PAD;
+        if (i < n) {
+            const int l = l0 + i / kin, j = i % kin;
+            v = LISTMAJOR ? in[((size_t)l * nq + q) * kin + j] : in[((size_t)q * L + l) * kin + j];
+        }
+        sb[i] = v;
+    }
+    __syncthreads();
+    wg_bitonic_sort(sb, P, tid, 256);
+    if (!final_round) {
+        uint64_t *o = out_keys + ((size_t)q * Lout + g) * k;
+        for (int i = tid; i < k; i += 256) o[i] = i < n ? sb[i] : KEY_PAD;
+        return;
+    }
+    for (int i = tid; i < max(k, out_key_fill); i += 256) {
+        const uint64_t key = i < k && i < n ? sb[i] : KEY_PAD;
+        if (out_keys) out_keys[(size_t)q * out_key_stride + i] = key;
+        if (D && i < k) {
+            const size_t o = (size_t)q * k + i;
             if (key == KEY_PAD) {
                 D[o] = metric == KNN_METRIC_INNER_PRODUCT ? -FLT_MAX : FLT_MAX;
                 I[o] = -1;
@@ -1278,6 +1391,13 @@ extern "C" int knn_flat_reconstruct(knn_handle h, int64_t i0, int64_t n, float *
 }
 
 // ---- search ---------------------------------------------------------------
+// Per-chunk survivor slots: chunks stop at "at most 1.25 k" keys (the merge is exact).  The
+// register select serves k <= 1536 (in the scan kernels lists of <= 2048 keys, 32 per lane, so
+// that 1.25 k + one tile fits; in the merge two slots per wave, <= 4096 keys); beyond that the
+// workgroup-sort paths take exactly k.
+static const int KNN_WAVE_SELECT_MAX_K = 1536;
+static int knn_kslot(int k) { return k > KNN_WAVE_SELECT_MAX_K ? k : k + k / 4; }
+
 static int next_pow2_host(int n)
 {
     int p = 64;
@@ -1297,7 +1417,10 @@ static int run_merge(const uint64_t *in, int L, int kin, int k, int64_t nq, bool
     bool lm = list_major;
     int round = 0;
     for (;;) {
-        const int G = std::max(2, 4096 / kin);
+        // wave path: two or more lists must fit one register select (4096 keys); otherwise
+        // (k > 1536) the workgroup sort handles up to 8192 keys per group
+        const bool wave_path = 2 * kin <= 4096;
+        const int G = wave_path ? std::max(2, 4096 / kin) : std::max(2, 8192 / kin);
         const int Lout = (L + G - 1) / G;
         const bool final_round = Lout == 1;
         uint64_t *out = nullptr;
@@ -1309,14 +1432,26 @@ static int run_merge(const uint64_t *in, int L, int kin, int k, int64_t nq, bool
             out = keys_out;
         }
         const int64_t items = nq * Lout;
-        const unsigned grid = (unsigned)((items + 3) / 4);
-        const size_t lds = final_round ? lds_final : 0;
-        if (lm) {
-            hipLaunchKernelGGL(merge_select_kernel<true>, dim3(grid), dim3(256), lds, s, in, L, kin, k, nq, G, Lout, out,
-                               final_round ? keys_out_stride : (int64_t)0, keys_out_fill, final_round ? 1 : 0, metric, D, I);
+        if (wave_path) {
+            const unsigned grid = (unsigned)((items + 3) / 4);
+            const size_t lds = final_round ? lds_final : 0;
+            if (lm)
+                hipLaunchKernelGGL(merge_select_kernel<true>, dim3(grid), dim3(256), lds, s, in, L, kin, k, nq, G, Lout, out,
+                                   final_round ? keys_out_stride : (int64_t)0, keys_out_fill, final_round ? 1 : 0, metric, D, I);
+            else
+                hipLaunchKernelGGL(merge_select_kernel<false>, dim3(grid), dim3(256), lds, s, in, L, kin, k, nq, G, Lout, out,
+                                   final_round ? keys_out_stride : (int64_t)0, keys_out_fill, final_round ? 1 : 0, metric, D, I);
         } else {
-            hipLaunchKernelGGL(merge_select_kernel<false>, dim3(grid), dim3(256), lds, s, in, L, kin, k, nq, G, Lout, out,
-                               final_round ? keys_out_stride : (int64_t)0, keys_out_fill, final_round ? 1 : 0, metric, D, I);
+            const size_t lds = (size_t)next_pow2_host(std::min(L, G) * kin) * 8;
+            if (lm) {
+                HIP_TRY(hipFuncSetAttribute((const void *)merge_sort_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(merge_sort_kernel<true>, dim3((unsigned)items), dim3(256), lds, s, in, L, kin, k, nq, G, Lout, out,
+                                   final_round ? keys_out_stride : (int64_t)0, keys_out_fill, final_round ? 1 : 0, metric, D, I);
+            } else {
+                HIP_TRY(hipFuncSetAttribute((const void *)merge_sort_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(merge_sort_kernel<false>, dim3((unsigned)items), dim3(256), lds, s, in, L, kin, k, nq, G, Lout, out,
+                                   final_round ? keys_out_stride : (int64_t)0, keys_out_fill, final_round ? 1 : 0, metric, D, I);
+            }
         }
         HIP_TRY(hipGetLastError());
         if (final_round) return 0;
@@ -1365,6 +1500,7 @@ static void make_plan(const knn_index_s *h, int64_t nb, int64_t nq, int k, bool 
     pl.nqtiles = (int)((nq + qt - 1) / qt);
     pl.cap = next_pow2_host(2 * k + pl.dt);
     if (pl.cap < 512) pl.cap = 512;
+    if (k <= KNN_WAVE_SELECT_MAX_K) pl.cap = std::min(pl.cap, 2048); // register select: <= 32 keys per lane
     const int64_t ntiles = (nb + pl.dt - 1) / pl.dt;
     int64_t want = h->force_chunks > 0 ? h->force_chunks : (1024 + pl.nqtiles - 1) / pl.nqtiles;
     // an unseeded chunk should see enough rows to amortise its threshold warm-up; a seeded pass
@@ -1416,9 +1552,7 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
                        int level, uint64_t *keys_out, int64_t keys_stride, int keys_fill, float *D_out, int64_t *I_out,
                        hipStream_t s)
 {
-    // per-chunk survivor slots: chunks stop at "at most 1.25 k" keys, the merge is exact
-    // (two slots must fit one wave_select: 2 * kslot <= 4096)
-    const int kslot = std::min(k + k / 4, 2048);
+    const int kslot = knn_kslot(k);
     const int64_t nb = (h->ntotal + row_mul - 1) / row_mul;
     ScanPlan pl;
     make_plan(h, nb, nq, k, true, pl);
