@@ -52,6 +52,22 @@ def parse():
 
 
 def main():
+    # stdout carries exactly ONE line (the JSON): everything libraries print while we run (RCCL's
+    # version banner, for one) is sent to stderr instead
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        line = run()
+    finally:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
+    if line is not None:
+        print(line, flush=True)
+
+
+def run():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -130,7 +146,7 @@ def main():
 
     if rank != 0:
         dist.destroy_process_group()
-        return
+        return None
 
     ms_per_step = 1e3 * elapsed / args.steps
     out = {
@@ -180,9 +196,9 @@ def main():
         del index
         torch.cuda.empty_cache()
         out["batch"] = batch_config(dev, L, _lib, faiss)
-    print(json.dumps(out))
     if use_pg:
         dist.destroy_process_group()
+    return json.dumps(out)
 
 
 def cpu_baseline(sample_rows, q_host, k, nb_total, D_gpu, I_gpu, index):

@@ -121,6 +121,9 @@ CASES = [
     (300, 5000, 1024, 301, 0, 0),
     (300, 5000, 1024, 1000, 0, 0),
     (40, 5000, 1024, 2048, 0, 0),
+    (33, 6000, 256, 1536, 0, 0),
+    (33, 6000, 256, 1537, 0, 0),
+    (130, 6000, 128, 1025, 0, 0),
     (77, 2049, 100, 13, 0, 0),
     (50, 700, 37, 11, 0, 0),
     (260, 4100, 128, 64, 0, 0),
@@ -142,6 +145,19 @@ def test_random_vs_oracle(gpu_faiss, oracle, nq, nb, d, k, qt, nch, metric):
     _assert_same(D, I, Do, Io)
 
 
+def test_query_batching_over_16384(gpu_faiss, oracle):
+    """Host searches run in batches of 16384 queries; results must not depend on it."""
+    rng = np.random.default_rng(41)
+    xb = rng.standard_normal((3000, 32), dtype=np.float32)
+    xq = rng.standard_normal((40000, 32), dtype=np.float32)
+    for metric in (0, 1):
+        idx = gpu_faiss.IndexFlat(32, metric)
+        idx.add(xb)
+        D, I = idx.search(xq, 7)
+        Do, Io = oracle.flat_search(xb, xq, 7, metric)
+        _assert_same(D, I, Do, Io)
+
+
 def test_register_staged_variant_matches(gpu_faiss, oracle):
     """flags=1 selects the register-staged (no LDS-DMA) build of the scan kernel."""
     rng = np.random.default_rng(5)
@@ -149,9 +165,11 @@ def test_register_staged_variant_matches(gpu_faiss, oracle):
     xq = rng.standard_normal((150, 1024), dtype=np.float32)
     for metric in (0, 1):
         idx = gpu_faiss.IndexFlat(1024, metric)
-        idx.set_tuning(0, 0, 1)
-        idx.add(xb)
-        _assert_same(*idx.search(xq, 50), *oracle.flat_search(xb, xq, 50, metric))
+        for flags in (1, 64, 256):  # register staged, register ring, radix-select experiment
+            idx.set_tuning(0, 0, flags)
+            if idx.ntotal == 0:
+                idx.add(xb)
+            _assert_same(*idx.search(xq, 50), *oracle.flat_search(xb, xq, 50, metric))
 
 
 def test_normalize_matches_oracle(gpu_faiss, oracle):
