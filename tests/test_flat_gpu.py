@@ -128,6 +128,9 @@ CASES = [
     (50, 700, 37, 11, 0, 0),
     (260, 4100, 128, 64, 0, 0),
     (32, 60000, 1024, 100, 0, 0),
+    (50, 3000, 1280, 11, 0, 0),   # ESM-1b width (cath/search.py searches every embedder's file)
+    (20, 1500, 2560, 11, 0, 0),
+    (9, 700, 4096, 5, 0, 0),
 ]
 
 
@@ -300,6 +303,13 @@ def test_cath20_sized_all_vs_all(gpu_faiss, oracle):
     sample = rng.choice(14433, 24, replace=False)
     Do, Io = oracle.flat_search(x, x[sample], 301, 1)
     _assert_same(scores[sample], hits[sample], Do[:, 1:], Io[:, 1:])
+    # and against fp64 truth: ids only permuted inside fp32-noise clusters, distances within
+    # 1e-5 of |x|^2+|y|^2 (the north star's tolerance; oracle/knn_oracle.py compare_tie_tolerant)
+    from oracle import knn_oracle as ko
+    full_I = np.concatenate([sample[:, None], hits[sample]], 1)
+    full_D = np.concatenate([np.zeros((24, 1), np.float32), scores[sample]], 1)
+    stats = ko.compare_tie_tolerant(full_I, full_D, x, x[sample], ko.METRIC_L2, dist_rtol=1e-5)
+    assert stats["max_dist_err_rel"] < 1e-5
     # cosine, reference default hits=10
     hits, scores = search(x, hits=10)
     xn = x.copy()
