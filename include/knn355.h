@@ -115,6 +115,9 @@ typedef struct knn_hnsw_s *knn_hnsw_handle;
 int knn_hnsw_create(int32_t d, int32_t M, int32_t metric, knn_hnsw_handle *out);
 /* index.hnsw.efSearch / index.hnsw.efConstruction (values <= 0 leave the setting alone) */
 int knn_hnsw_set_ef(knn_hnsw_handle h, int32_t efSearch, int32_t efConstruction);
+/* walk tuning (not in faiss): candidates expanded per walker per lock-step round (default 8;
+ * 1 = strict best-first) and walkers per batch (default 4096); values <= 0 keep the setting */
+int knn_hnsw_set_walk(knn_hnsw_handle h, int32_t expand, int32_t max_batch);
 int knn_hnsw_get_params(knn_hnsw_handle h, int32_t *M, int32_t *efSearch, int32_t *efConstruction,
                         int32_t *max_level, int64_t *entry_point);
 int knn_hnsw_add(knn_hnsw_handle h, const float *x_host, int64_t n);

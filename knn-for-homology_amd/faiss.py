@@ -210,6 +210,10 @@ class IndexHNSWFlat(Index):
         _lib.check(_lib.lib().knn_hnsw_search(self._h, x.ctypes.data, x.shape[0], k, D.ctypes.data, I.ctypes.data))
         return D, I
 
+    def set_walk(self, expand=0, max_batch=0):
+        """knn355 extra: candidates expanded per walker per lock-step round / walkers per batch."""
+        _lib.check(_lib.lib().knn_hnsw_set_walk(self._h, int(expand), int(max_batch)))
+
     def reconstruct_n(self, i0=0, n=None):
         n = self.ntotal - i0 if n is None else n
         out = np.empty((n, self._d), np.float32)

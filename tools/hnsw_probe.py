@@ -47,15 +47,16 @@ def main():
         levels, offsets, nbrs, cum, _ = idx.graph()
         deg0 = [(nbrs[offsets[i]:offsets[i] + cum[1]] >= 0).sum() for i in range(0, n, max(1, n // 2000))]
         print(f"metric={metric} n={n} d={d} M={M}: build {tb:.2f}s  {st}  max_level={idx.hnsw.max_level} mean deg0={np.mean(deg0):.1f}", flush=True)
-        for efs, k in ((16, 10), (64, 10), (256, 100), (256, 10)):
+        for efs, k, ex in ((16, 10, 4), (64, 10, 4), (256, 100, 1), (256, 100, 2), (256, 100, 4), (256, 100, 8), (256, 10, 4)):
             idx.hnsw.efSearch = efs
+            idx.set_walk(ex, 0)
             t0 = time.time()
             D, I = idx.search(x[:nq], k)
             ts = time.time() - t0
             st = idx.stats(reset=True)
             r = recall(I, It[:, :k])
             same = np.array_equal(D[:, 0], Dt[:, 0])
-            print(f"   efSearch={efs:4d} k={k:4d}: {ts:.3f}s ({nq/ts:.0f} q/s; flat {nq/tf:.0f} q/s) recall@{k}={r:.4f} top1dist_equal={same} rounds={st['rounds']} pairs={st['pairs']} gpu={st['gpu_s']:.3f}s host={st['host_s']:.3f}s", flush=True)
+            print(f"   efSearch={efs:4d} k={k:4d} expand={ex}: {ts:.3f}s ({nq/ts:.0f} q/s; flat {nq/tf:.0f} q/s) recall@{k}={r:.4f} top1dist_equal={same} rounds={st['rounds']} pairs={st['pairs']} gpu={st['gpu_s']:.3f}s host={st['host_s']:.3f}s", flush=True)
 
 
 if __name__ == "__main__":
