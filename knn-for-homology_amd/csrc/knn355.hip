@@ -26,6 +26,7 @@
 //                        last round sorts and writes D / I.
 //   hnsw.inc / lsh.inc / eval.inc   IndexHNSWFlat, IndexLSH, consumers of (hits, scores).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -567,6 +568,17 @@ __device__ __forceinline__ void stage_issue(const float *src, char *lds_wave_bas
     }
 }
 
+// scheduling pattern "PER MFMAs, one vector-memory instruction", N times
+template <int N, int PER>
+__device__ __forceinline__ void sched_spread()
+{
+    if constexpr (N > 0) {
+        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        sched_spread<N - 1, PER>();
+    }
+}
+
 // WM x WN waves; each wave owns TM x TN MFMA tiles of 32(db rows) x 32(queries)
 // SAMPLE only names the instantiation that scans a seed sample, so that profiles keep the
 // (tiny) sample launches apart from the main pass of the same configuration.
@@ -610,7 +622,6 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
     L.use_hist = (p.dbg & 256) != 0; // experiment: LDS-histogram radix select instead of the bitwise search
     L.init(tid, QT);
     __syncthreads();
-
     // per-lane staging bookkeeping: instruction ii covers combined rows 8*ii..8*ii+7
     const float *srcp[NI];
     int lds_off[NI];
@@ -657,35 +668,70 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
                 tsrc[n] = srcp[n];
             }
         }
-        auto compute = [&](const char *cur) {
+        // One K step of MFMA work from buffer `cur`.  `dma(n)` (n < NI) issues this wave's n-th
+        // staging instruction of the NEXT K step; the NI of them are spread between the MFMAs so
+        // that their issue cost (60-180 cycles each) is paid while the matrix pipe is busy, not
+        // in front of it.  ND = 0: nothing to stage.
+        auto compute = [&](const char *cur, auto &&dma, auto nd_tag) {
+            constexpr int ND = decltype(nd_tag)::value;
             const char *A = cur;
             const char *B = cur + DT * 128;
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                f32x4 af[TM], bf[TN];
+            // fragments of sub-step t+1 are requested before the MFMAs of sub-step t are issued,
+            // so the LDS latency hides behind the matrix pipe (two register sets, fully unrolled)
+            f32x4 af[2][TM], bf[2][TN];
+            auto frag = [&](int t) {
                 const int slot = ((2 * t + lh) ^ swz) * 16;
 #pragma unroll
                 for (int a = 0; a < TM; a++)
-                    af[a] = *(const f32x4 *)(A + ((wm * TM + a) * 32 + li) * 128 + slot);
+                    af[t & 1][a] = *(const f32x4 *)(A + ((wm * TM + a) * 32 + li) * 128 + slot);
 #pragma unroll
                 for (int b = 0; b < TN; b++)
-                    bf[b] = *(const f32x4 *)(B + ((wn * TN + b) * 32 + li) * 128 + slot);
-                if (p.dbg & 128) { // timing experiment: fragments read, no MFMA
+                    bf[t & 1][b] = *(const f32x4 *)(B + ((wn * TN + b) * 32 + li) * 128 + slot);
+            };
+            constexpr int M = 4 * TM * TN; // MFMAs per sub-step
+            frag(0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+            auto substep = [&](auto t_tag) {
+                constexpr int t = decltype(t_tag)::value;
+                if constexpr (t < 3) frag(t + 1);
+#ifdef KNN355_ABLATE_MFMA // timing experiment: fragments read, no MFMA
 #pragma unroll
-                    for (int a = 0; a < TM; a++) asm volatile("" ::"v"(af[a]));
+                for (int a = 0; a < TM; a++) asm volatile("" ::"v"(af[t & 1][a]));
 #pragma unroll
-                    for (int b = 0; b < TN; b++) asm volatile("" ::"v"(bf[b]));
-                    continue;
-                }
+                for (int b = 0; b < TN; b++) asm volatile("" ::"v"(bf[t & 1][b]));
+#else
 #pragma unroll
                 for (int m = 0; m < 4; m++)
 #pragma unroll
                     for (int a = 0; a < TM; a++)
 #pragma unroll
                         for (int b = 0; b < TN; b++)
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][m], bf[b][m], acc[a][b], 0, 0, 0);
-            }
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t & 1][a][m], bf[t & 1][b][m], acc[a][b], 0, 0, 0);
+#endif
+                // staging instructions [n0, n1) of the next K step belong to this sub-step; all of
+                // them go out in the first half of the K step so that the second half covers
+                // their latency before the next barrier's vmcnt(0)
+                constexpr int TD = 2;
+                constexpr int n0 = t < TD ? ND * t / TD : ND, n1 = t < TD ? ND * (t + 1) / TD : ND;
+#pragma unroll
+                for (int n = n0; n < n1; n++) dma(n);
+                // pin the order: LDS reads of t+1, then the MFMAs of t with the staging
+                // instructions spread between them (left alone, the scheduler sinks the reads
+                // behind the MFMAs to save registers and the wait is exposed)
+                if constexpr (t < 3) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+                constexpr int nd = n1 - n0, per = M / (nd + 1);
+                static_assert(per >= 1, "more staging instructions than MFMAs in a sub-step");
+                sched_spread<nd, per>();
+                __builtin_amdgcn_sched_group_barrier(0x008, M - nd * per, 0);
+            };
+            substep(std::integral_constant<int, 0>{});
+            substep(std::integral_constant<int, 1>{});
+            substep(std::integral_constant<int, 2>{});
+            substep(std::integral_constant<int, 3>{});
         };
+        auto no_dma = [](int) {};
+        using nd_none = std::integral_constant<int, 0>;
+        using nd_all = std::integral_constant<int, NI>;
         if constexpr (STG == 2) {
             // Register ring: stage s+1 and s+2 are in flight in VGPRs while stage s is multiplied
             // from LDS -- twice the bytes in flight of the double-buffered LDS-DMA form without
@@ -718,7 +764,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 #pragma unroll
                     for (int n = 0; n < NI; n++) rs[n] = *(gptr4)(tsrc[n] + sn);
                 }
-                compute(cur);
+                compute(cur, no_dma, nd_none{});
             };
             for (int kt = 0; kt + 1 < KT; kt += 2) {
                 step(kt, ra);
@@ -733,17 +779,26 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
                 stage_issue<GLDS>(tsrc[n], stage0 + lds_off[n], lane, sreg[n]);
                 if constexpr (!GLDS) *(f32x4 *)(stage0 + lds_off[n] + lane * 16) = sreg[n];
             }
-            for (int kt = 0; kt < KT; kt++) {
-                char *cur = (kt & 1) ? stage1 : stage0;
-                char *nxt = (kt & 1) ? stage0 : stage1;
-                __syncthreads(); // stage kt landed (vmcnt(0) + barrier); buffer nxt is free
-                if (kt + 1 < KT) {
-#pragma unroll
-                    for (int n = 0; n < NI; n++)
-                        stage_issue<GLDS>(tsrc[n] + (kt + 1) * 32, nxt + lds_off[n], lane, sreg[n]);
+            if constexpr (GLDS) {
+                for (int kt = 0; kt + 1 < KT; kt++) {
+                    char *cur = (kt & 1) ? stage1 : stage0;
+                    char *nxt = (kt & 1) ? stage0 : stage1;
+                    __syncthreads(); // stage kt landed (vmcnt(0) + barrier); buffer nxt is free
+                    const int koff = (kt + 1) * 32;
+                    compute(cur, [&](int n) { stage_issue<true>(tsrc[n] + koff, nxt + lds_off[n], lane, sreg[n]); }, nd_all{});
                 }
-                compute(cur);
-                if constexpr (!GLDS) {
+                __syncthreads();
+                compute(((KT - 1) & 1) ? stage1 : stage0, no_dma, nd_none{});
+            } else {
+                for (int kt = 0; kt < KT; kt++) {
+                    char *cur = (kt & 1) ? stage1 : stage0;
+                    char *nxt = (kt & 1) ? stage0 : stage1;
+                    __syncthreads(); // stage kt is in LDS for everyone; buffer nxt is free
+                    if (kt + 1 < KT) {
+#pragma unroll
+                        for (int n = 0; n < NI; n++) stage_issue<false>(tsrc[n] + (kt + 1) * 32, nxt + lds_off[n], lane, sreg[n]);
+                    }
+                    compute(cur, no_dma, nd_none{});
                     if (kt + 1 < KT) {
 #pragma unroll
                         for (int n = 0; n < NI; n++) *(f32x4 *)(nxt + lds_off[n] + lane * 16) = sreg[n];
@@ -1521,7 +1576,10 @@ static void make_plan(const knn_index_s *h, int64_t nb, int64_t nq, int k, bool 
         int64_t best = want, best_cost = INT64_MAX;
         for (int64_t c = std::max<int64_t>(1, want / 2); c <= std::min(want_max, want + want / 2 + 1); c++) {
             const int64_t rounds = (pl.nqtiles * c + slots - 1) / slots;
-            const int64_t cost = rounds * ((ntiles + c - 1) / c);
+            // per chunk: its tiles + about half a tile of fixed work (prologue, cutting the lists
+            // and writing the survivors) -- 1.25 M rows x 32 queries: 489 chunks of 10 tiles in
+            // one round beat 977 chunks of 5 tiles in two
+            const int64_t cost = rounds * (2 * ((ntiles + c - 1) / c) + 1);
             if (cost < best_cost || (cost == best_cost && c > best)) { best = c; best_cost = cost; }
         }
         want = best;
@@ -1598,7 +1656,7 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     p.skip_mask = sstride ? sstride - 1 : -1;
     p.partial_lists = nlists;
     p.kslot = kslot;
-    p.dbg = h->flags & (6 | 128 | 256);
+    p.dbg = h->flags & (6 | 256);
     const bool top = level == 0;
     if (top) {
         const int slot = (int)(h->nlaunches % knn_index_s::RING);

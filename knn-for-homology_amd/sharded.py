@@ -15,6 +15,7 @@ slices in insertion order, so global ids are ``row_offset + local row``.  A sear
 
 torch is used for device memory, the current stream and torch.distributed only.
 """
+import contextlib
 import ctypes
 import os
 
@@ -40,6 +41,28 @@ class HipShardBackend:
         self.index = _faiss.IndexFlat(d, metric)
         self.metric = metric
         self.device = torch.device("cuda", int(_lib.lib().knn_device_of(self.index._h)))
+        self._stream = None
+
+    @contextlib.contextmanager
+    def stream_scope(self, *inputs):
+        """Runs the enclosed launches on the backend's own (non-default) HIP stream, ordered
+        after the caller's current stream, and makes the caller's stream wait for them on exit.
+        The C ABI treats a NULL stream as "use the library's stream and synchronise"; torch's
+        default stream IS the NULL stream, so without this every search would block the host
+        and the GPU would idle between the kernels of consecutive searches."""
+        caller = torch.cuda.current_stream(self.device)
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(self.device)
+        side = self._stream
+        side.wait_stream(caller)
+        for t in inputs:
+            t.record_stream(side)
+        outs = []
+        with torch.cuda.stream(side):
+            yield outs
+        caller.wait_stream(side)
+        for t in outs:
+            t.record_stream(caller)
 
     def reserve(self, n):
         _lib.check(_lib.lib().knn_flat_reserve(self.index._h, n))
@@ -119,14 +142,19 @@ class ShardedFlatIndex:
         """q: [nq, d] float32 tensor, identical on every rank.  Returns (D, I) tensors
         holding the global result on every rank."""
         k = int(k)
-        if self.world == 1 and not self.force_collective:
-            return self.backend.search(q, k)
-        nq = q.shape[0]
-        keys = self.backend.search_keys(q, k, self.row_offset)
-        # rank-major concatenation along dim 0 == [world, nq, k]
-        gathered = torch.empty((self.world * nq, k), dtype=torch.int64, device=keys.device)
-        dist.all_gather_into_tensor(gathered, keys, group=self.group)
-        return self.backend.merge(gathered.view(self.world, nq, k), self.world, nq, k)
+        scope = getattr(self.backend, "stream_scope", None)
+        with (scope(q) if scope else contextlib.nullcontext([])) as outs:
+            if self.world == 1 and not self.force_collective:
+                D, I = self.backend.search(q, k)
+            else:
+                nq = q.shape[0]
+                keys = self.backend.search_keys(q, k, self.row_offset)
+                # rank-major concatenation along dim 0 == [world, nq, k]
+                gathered = torch.empty((self.world * nq, k), dtype=torch.int64, device=keys.device)
+                dist.all_gather_into_tensor(gathered, keys, group=self.group)
+                D, I = self.backend.merge(gathered.view(self.world, nq, k), self.world, nq, k)
+            outs += [D, I]
+        return D, I
 
     def search(self, x: np.ndarray, k):
         _faiss._check_matrix(x, self.d)
