@@ -26,6 +26,7 @@
 //                        last round sorts and writes D / I.
 //   hnsw.inc / lsh.inc / eval.inc   IndexHNSWFlat, IndexLSH, consumers of (hits, scores).
 #include <hip/hip_runtime.h>
+#include <thread>
 #include <type_traits>
 #include <stdint.h>
 #include <stdio.h>
@@ -287,6 +288,22 @@ __device__ __attribute__((noinline)) int wave_select(LD load, int n, int k, int 
     };
     uint32_t T = mx;
     int cnt = n;
+    if (mx == 0xFFFFFFFFu && mn != mx) {
+        // padded input (merge of per-chunk lists, mostly padding after a seeded scan): if no
+        // more than kmax real keys exist they all survive and there is nothing to search;
+        // otherwise search only the bit range of the real keys
+        const int real = count_lt(0xFFFFFFFFu);
+        if (real <= kmax) {
+            mn = mx; // skip the search: T = 0xFFFFFFFF keeps every real key
+        } else {
+            uint32_t mr = 0u;
+#pragma unroll
+            for (int r = 0; r < R; r++) mr = max(mr, hi[r] == 0xFFFFFFFFu ? 0u : hi[r]);
+            mx = wave_max_u32(mr);
+            T = mx;
+            cnt = real;
+        }
+    }
     if (mn != mx && hist) {
         // Experiment (flags & 256): byte-wise radix select through a 256-bin LDS histogram private
         // to this wave: at most four passes (leading bytes shared by all keys are skipped), each
@@ -444,12 +461,31 @@ struct ScanParams {
     uint32_t *gthr;    // [nqtiles*QT] shared running thresholds (order-mapped floats)
     uint64_t *partial; // [nq][nchunks][k]
     uint32_t id_base;
-    int row_mul;       // this launch scans the strided view rows r*row_mul (r < nb)
-    int skip_mask;     // >= 0: rows with (r & skip_mask) == 0 belong to the seed sample, skip them
+    int row_mul;       // this launch scans a block-strided view of the database, see view_row()
+    int skip_mask;     // >= 0: rows whose 8-row block b has (b & skip_mask) == 0 belong to the seed sample, skip them
     int kslot;         // keys per (query, list) slot in `partial`: k + k/4
     int partial_lists; // lists per query in `partial` (nchunks, +1 when a seed list rides along)
     int dbg;           // timing experiments only: 2 = skip compaction, 4 = skip appends
 };
+
+// Views: view row r of a launch with stride row_mul is database row
+// (r / 8) * 8 * row_mul + r % 8 -- blocks of 8 consecutive rows, every row_mul-th block
+// (row_mul = 1: the database itself).  Blocks rather than single rows because one staging
+// instruction fetches 8 rows: 8 rows 32 KB apart in one page instead of 8 pages (a row-strided
+// sample of a 41 GB database ran at 1.9 TB/s, bound by address translation).
+#define KNN_VIEW_BLOCK_SHIFT 3
+__host__ __device__ __forceinline__ int64_t view_row(int64_t r, int row_mul)
+{
+    return ((r >> KNN_VIEW_BLOCK_SHIFT) * row_mul << KNN_VIEW_BLOCK_SHIFT) + (r & ((1 << KNN_VIEW_BLOCK_SHIFT) - 1));
+}
+// rows of the view with stride row_mul over a database of n rows
+static inline int64_t view_rows(int64_t n, int row_mul)
+{
+    const int64_t B = 1 << KNN_VIEW_BLOCK_SHIFT, span = B * row_mul;
+    if (n <= 0) return 0;
+    const int64_t last = (n - 1) / span; // last block that starts inside the database
+    return last * B + std::min<int64_t>(B, n - last * span);
+}
 
 // ---- per-workgroup candidate lists shared by the scan kernels -------------------------
 // s_thr / s_cnt / s_need live in LDS, the lists themselves in global memory (L2).
@@ -662,7 +698,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 #pragma unroll
         for (int n = 0; n < NI; n++) {
             if (is_db[n]) {
-                int64_t r = min(row0 + rloc[n], p.nb - 1) * p.row_mul;
+                int64_t r = view_row(min(row0 + rloc[n], p.nb - 1), p.row_mul);
                 tsrc[n] = srcp[n] + r * p.dp;
             } else {
                 tsrc[n] = srcp[n];
@@ -824,15 +860,15 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
                     const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
                     float v;
                     if constexpr (L2) {
-                        float ynr = p.yn[min(row, p.nb - 1) * p.row_mul];
+                        float ynr = p.yn[view_row(min(row, p.nb - 1), p.row_mul)];
                         float t = xnq + ynr;
                         v = __builtin_fmaf(-2.0f, acc[a][b][r], t);
                         v = v < 0.0f ? 0.0f : v;
                     } else {
                         v = -acc[a][b][r];
                     }
-                    if (v <= thr && row < c_hi && qok && !(p.skip_mask >= 0 && ((int)row & p.skip_mask) == 0) && !(p.dbg & 4))
-                        L.append(ql, v, p.id_base + (uint32_t)row * (uint32_t)p.row_mul, DT);
+                    if (v <= thr && row < c_hi && qok && !(p.skip_mask >= 0 && ((int)(row >> KNN_VIEW_BLOCK_SHIFT) & p.skip_mask) == 0) && !(p.dbg & 4))
+                        L.append(ql, v, p.id_base + (uint32_t)view_row(row, p.row_mul), DT);
                 }
             }
         }
@@ -1147,12 +1183,17 @@ struct knn_index_s {
     float *yn = nullptr; // [cap_rows + pad]
     size_t xb_bytes = 0, yn_bytes = 0; // allocation sizes (may exceed the row capacity: pooled)
     hipStream_t stream = nullptr;
+    // host-buffer searches: query upload and result download run beside the scan of the
+    // neighbouring batch (own streams, two sets of staging buffers, see knn_flat_search)
+    hipStream_t stream_h2d = nullptr, stream_d2h = nullptr;
+    hipEvent_t ev_query[2] = {nullptr, nullptr}, ev_batch[2] = {nullptr, nullptr};
     hipEvent_t ev0 = nullptr, ev1 = nullptr; // the pair of the most recent scan launch
     static const int RING = 64;
     hipEvent_t ring0[RING] = {nullptr}, ring1[RING] = {nullptr};
     int64_t nlaunches = 0;
     std::mutex mu;
     DevBuf ws_q, ws_qn, ws_lists, ws_gthr, ws_partial, ws_partial2, ws_keys, ws_D, ws_I, ws_tmp, ws_tmp2;
+    DevBuf ws_D1, ws_I1, ws_tmp3; // second set for the pipelined host search
     DevBuf ws_level[8]; // per seed-recursion level: [nq][lists][k] survivor keys
     int last_seed_stride = 0;
     // tuning + introspection
@@ -1304,8 +1345,14 @@ extern "C" void knn_free(knn_handle h)
     if (hipSetDevice(h->device) == hipSuccess) {
         free_index_buffers(h);
         DevBuf *bufs[] = {&h->ws_q, &h->ws_qn, &h->ws_lists, &h->ws_gthr, &h->ws_partial, &h->ws_partial2,
-                          &h->ws_keys, &h->ws_D, &h->ws_I, &h->ws_tmp, &h->ws_tmp2};
+                          &h->ws_keys, &h->ws_D, &h->ws_I, &h->ws_tmp, &h->ws_tmp2, &h->ws_D1, &h->ws_I1, &h->ws_tmp3};
         for (DevBuf *b : bufs) b->release();
+        for (int i = 0; i < 2; i++) {
+            if (h->ev_query[i]) (void)hipEventDestroy(h->ev_query[i]);
+            if (h->ev_batch[i]) (void)hipEventDestroy(h->ev_batch[i]);
+        }
+        if (h->stream_h2d) (void)hipStreamDestroy(h->stream_h2d);
+        if (h->stream_d2h) (void)hipStreamDestroy(h->stream_d2h);
         for (DevBuf &b : h->ws_level) b.release();
         for (int i = 0; i < knn_index_s::RING; i++) {
             if (h->ring0[i]) (void)hipEventDestroy(h->ring0[i]);
@@ -1591,7 +1638,7 @@ static void make_plan(const knn_index_s *h, int64_t nb, int64_t nq, int k, bool 
     pl.lds = std::max((size_t)2 * (pl.dt + pl.qt) * 128, (size_t)pl.cap * 8) + (size_t)qt * 8 + 16;
 }
 
-// Seed stride of a view with nb rows: a power of two s such that the sample (every s-th row)
+// Seed stride of a view with nb rows: a power of two s such that the sample (every s-th 8-row block)
 // has about max(2 * chunk_rows, 64 k) rows (and at most nb/8).  The sample is searched first,
 // exactly; its k-th score bounds the global k-th from above, so every chunk of the main pass
 // starts with a tight threshold and appends about chunk_rows * k / sample_rows <= k/2
@@ -1604,14 +1651,13 @@ static int seed_stride(int64_t nb, int k, int64_t chunk_rows)
     return s;
 }
 
-// Exact top-k of the strided view {r * row_mul : r < ceil(ntotal / row_mul)} for queries
+// Exact top-k of the block-strided view (view_row) with stride row_mul for queries
 // [nq][dp] on the device.  Output: sorted keys (keys_out, per-query stride keys_stride) and/or D/I.
 static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int64_t nq, int k, uint32_t id_base, int row_mul,
                        int level, uint64_t *keys_out, int64_t keys_stride, int keys_fill, float *D_out, int64_t *I_out,
                        hipStream_t s)
 {
-    const int kslot = knn_kslot(k);
-    const int64_t nb = (h->ntotal + row_mul - 1) / row_mul;
+    const int64_t nb = view_rows(h->ntotal, row_mul);
     ScanPlan pl;
     make_plan(h, nb, nq, k, true, pl);
     if (level >= (int)(sizeof(h->ws_level) / sizeof(h->ws_level[0]))) return set_err(KNN_ERR_INVALID, "search: seed recursion too deep");
@@ -1624,6 +1670,12 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     if (h->flags & 8) seed = false;
     if (!seed) make_plan(h, nb, nq, k, level > 0, pl); // a seed sample is small: parallelism over warm-up
     const int sstride = seed ? seed_stride(nb, k, pl.chunk_rows) : 0;
+    // Keys per (query, chunk) slot.  Chunks of a single tile (a seed sample, a tiny database)
+    // hand ALL their rows to the merge: cutting 32 lists of one tile down to 1.25 k at the end
+    // of the only tile is serial work per workgroup (8 selects per wave, ~40 us) that the merge's
+    // first round does anyway, with one wave per (query, group).
+    int kslot = knn_kslot(k);
+    if (pl.chunk_rows == pl.dt && pl.dt > kslot && pl.dt <= pl.cap - pl.dt && k <= KNN_WAVE_SELECT_MAX_K) kslot = pl.dt;
     const int nlists = pl.nchunks + (sstride ? 1 : 0);
     DevBuf &pbuf = h->ws_level[level];
     if (pbuf.ensure((size_t)nq * nlists * kslot * 8)) return set_err(KNN_ERR_HIP, "search: out of device memory");
@@ -1795,25 +1847,93 @@ extern "C" int knn_flat_search(knn_handle h, const float *q_host, int64_t nq, in
     if (nq == 0) return 0;
     std::lock_guard<std::mutex> lk(h->mu);
     HIP_TRY(hipSetDevice(h->device));
-    // query batches bound the device workspace; 16384 queries keep >= 128 query tiles in flight
+    // Query batches bound the device workspace; 16384 queries keep >= 128 query tiles in flight.
+    // Batches are pipelined: while batch b is scanned, a helper thread downloads the results of
+    // batch b-1 (pageable host memory: the copy blocks its caller) and this thread uploads the
+    // queries of batch b+1, each on its own stream with its own staging buffers.
     const int64_t QB = 16384;
     const int64_t bq = std::min(nq, QB);
-    if (h->ws_tmp2.ensure((size_t)bq * h->d * 4) || h->ws_D.ensure((size_t)bq * k * 4) || h->ws_I.ensure((size_t)bq * k * 8))
-        return set_err(KNN_ERR_HIP, "search: out of device memory");
-    float ms_total = 0.f;
-    for (int64_t b0 = 0; b0 < nq; b0 += QB) {
-        int64_t m = std::min(QB, nq - b0);
-        HIP_TRY(hipMemcpyAsync(h->ws_tmp2.p, q_host + b0 * h->d, (size_t)m * h->d * 4, hipMemcpyHostToDevice, h->stream));
-        rc = search_dev_impl(h, (const float *)h->ws_tmp2.p, m, (int)k, (float *)h->ws_D.p, (int64_t *)h->ws_I.p, nullptr, 0, h->stream);
+    const int64_t nbatches = (nq + QB - 1) / QB;
+    DevBuf *qbuf[2] = {&h->ws_tmp2, &h->ws_tmp3}, *dbuf[2] = {&h->ws_D, &h->ws_D1}, *ibuf[2] = {&h->ws_I, &h->ws_I1};
+    const int nslots = nbatches > 1 ? 2 : 1;
+    for (int i = 0; i < nslots; i++)
+        if (qbuf[i]->ensure((size_t)bq * h->d * 4) || dbuf[i]->ensure((size_t)bq * k * 4) || ibuf[i]->ensure((size_t)bq * k * 8))
+            return set_err(KNN_ERR_HIP, "search: out of device memory");
+    if (nbatches == 1) {
+        // nothing to overlap with: one stream, no helper thread, no extra HSA queues (callers such
+        // as cath/search.py build a fresh index per embedding file and search it once)
+        HIP_TRY(hipMemcpyAsync(qbuf[0]->p, q_host, (size_t)nq * h->d * 4, hipMemcpyHostToDevice, h->stream));
+        rc = search_dev_impl(h, (const float *)qbuf[0]->p, nq, (int)k, (float *)dbuf[0]->p, (int64_t *)ibuf[0]->p, nullptr, 0, h->stream);
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(D_host + b0 * k, h->ws_D.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipMemcpyAsync(I_host + b0 * k, h->ws_I.p, (size_t)m * k * 8, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(D_host, dbuf[0]->p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(I_host, ibuf[0]->p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
-        if (h->ntotal > 0 && h->ev0) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) ms_total += ms;
+        float ms = 0.f;
+        h->last_ms = (h->ntotal > 0 && h->ev0 && hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) ? ms : 0.f;
+        return 0;
+    }
+    if (!h->stream_h2d) {
+        HIP_TRY(hipStreamCreateWithFlags(&h->stream_h2d, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&h->stream_d2h, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) {
+            HIP_TRY(hipEventCreateWithFlags(&h->ev_query[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&h->ev_batch[i], hipEventDisableTiming));
         }
     }
+    struct Download {
+        std::thread th;
+        hipError_t err = hipSuccess;
+        hipEvent_t t0 = nullptr, t1 = nullptr; // scan events of the batch
+    } dl[2];
+    float ms_total = 0.f;
+    hipError_t dl_err = hipSuccess;
+    auto join = [&](int slot) {
+        if (!dl[slot].th.joinable()) return;
+        dl[slot].th.join();
+        if (dl[slot].err != hipSuccess) dl_err = dl[slot].err;
+        float ms = 0.f;
+        if (dl[slot].t0 && hipEventElapsedTime(&ms, dl[slot].t0, dl[slot].t1) == hipSuccess) ms_total += ms;
+    };
+    auto upload = [&](int64_t b) -> hipError_t {
+        const int slot = (int)(b & 1);
+        const int64_t b0 = b * QB, m = std::min(QB, nq - b0);
+        hipError_t e = hipMemcpyAsync(qbuf[slot]->p, q_host + b0 * h->d, (size_t)m * h->d * 4, hipMemcpyHostToDevice, h->stream_h2d);
+        if (e == hipSuccess) e = hipEventRecord(h->ev_query[slot], h->stream_h2d);
+        return e;
+    };
+    hipError_t e = upload(0);
+    for (int64_t b = 0; b < nbatches && e == hipSuccess && rc == 0; b++) {
+        const int slot = (int)(b & 1);
+        const int64_t b0 = b * QB, m = std::min(QB, nq - b0);
+        e = hipStreamWaitEvent(h->stream, h->ev_query[slot], 0);
+        if (e != hipSuccess) break;
+        rc = search_dev_impl(h, (const float *)qbuf[slot]->p, m, (int)k, (float *)dbuf[slot]->p, (int64_t *)ibuf[slot]->p, nullptr, 0, h->stream);
+        if (rc) break;
+        e = hipEventRecord(h->ev_batch[slot], h->stream);
+        if (e != hipSuccess) break;
+        dl[slot].t0 = h->ntotal > 0 ? h->ev0 : nullptr;
+        dl[slot].t1 = h->ev1;
+        dl[slot].err = hipSuccess;
+        dl[slot].th = std::thread([=, &dl]() {
+            hipError_t r = hipSetDevice(h->device);
+            if (r == hipSuccess) r = hipEventSynchronize(h->ev_batch[slot]);
+            if (r == hipSuccess) r = hipMemcpyAsync(D_host + b0 * k, dbuf[slot]->p, (size_t)m * k * 4, hipMemcpyDeviceToHost, h->stream_d2h);
+            if (r == hipSuccess) r = hipMemcpyAsync(I_host + b0 * k, ibuf[slot]->p, (size_t)m * k * 8, hipMemcpyDeviceToHost, h->stream_d2h);
+            if (r == hipSuccess) r = hipStreamSynchronize(h->stream_d2h);
+            dl[slot].err = r;
+        });
+        if (b + 1 < nbatches) {
+            // the other slot's buffers: its scan (batch b-1) must be over and downloaded
+            join(slot ^ 1);
+            e = upload(b + 1);
+        }
+    }
+    join(0);
+    join(1);
+    if (rc) return rc;
+    if (e != hipSuccess) return set_err(KNN_ERR_HIP, std::string("search: ") + hipGetErrorString(e));
+    if (dl_err != hipSuccess) return set_err(KNN_ERR_HIP, std::string("search: result download failed: ") + hipGetErrorString(dl_err));
+    HIP_TRY(hipStreamSynchronize(h->stream));
     h->last_ms = ms_total;
     return 0;
 }

@@ -16,7 +16,8 @@ from knn_for_homology_amd import faiss, _lib  # noqa: E402
 
 L = _lib.lib()
 dev = torch.device("cuda:0")
-sizes = [int(a) for a in sys.argv[1:]] or [1_250_000, 2_500_000, 5_000_000]
+sizes = [int(a) for a in sys.argv[1:] if "=" not in a] or [1_250_000, 2_500_000, 5_000_000]
+FLAGS = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("flags=")] or [0, 8, 16]
 g = torch.Generator(device=dev); g.manual_seed(3)
 q = torch.randn((32, 1024), generator=g, device=dev)
 _lib.check(L.knn_normalize_l2_dev(q.data_ptr(), 32, 1024, None))
@@ -32,7 +33,7 @@ for nb in sizes:
         _lib.check(L.knn_flat_add_dev(idx._h, x.data_ptr(), m, None))
         del x
     keys = torch.empty((32, 100), dtype=torch.int64, device=dev)
-    for flags in (0, 8, 16):
+    for flags in FLAGS:
         idx.set_tuning(0, 0, flags)
         res = []
         for rep in range(3):
