@@ -82,6 +82,17 @@ int knn_flat_search(knn_handle h, const float *q_host, int64_t nq, int64_t k, fl
                     int64_t *I_host);
 int knn_flat_search_dev(knn_handle h, const float *q_dev, int64_t nq, int64_t k, float *D_dev,
                         int64_t *I_dev, void *stream);
+/* All-vs-all without the round trips: the reference searches the very array it
+ * just added (cath/search.py:22-24 index.add(embeddings); index.search(embeddings,
+ * hits + 1); pfam/proteins_search.py:37,49).  knn_flat_search_self uses rows
+ * [row0, row0 + nrows) of the index, already resident and padded, as the queries --
+ * same results as knn_flat_search on those rows, no query upload.
+ * knn_flat_normalize_rows L2-normalises the stored rows in place on the device
+ * (cath/search.py:17-19 normalises a private copy before add: add the raw rows,
+ * normalise them here, and the caller's array stays untouched as in the reference). */
+int knn_flat_search_self(knn_handle h, int64_t row0, int64_t nrows, int64_t k, float *D_host,
+                         int64_t *I_host);
+int knn_flat_normalize_rows(knn_handle h);
 /* per-shard result as packed sortable keys (uint64: order-preserving score
  * bits << 32 | id_base + local row), k per query, ascending = best first,
  * padded with UINT64_MAX.  This is what ranks exchange (RCCL all-gather). */

@@ -4,8 +4,9 @@
   * one extra neighbour is requested and column 0 (the self hit) is dropped,
   * the return order is ``(hits int64 [N,hits], scores float32 [N,hits])`` -- ids first,
     i.e. swapped relative to ``index.search``,
-  * for the inner-product metric the rows are L2-normalised on a COPY (the caller's
-    array is left alone); for L2 nothing is normalised.
+  * for the inner-product metric the rows are L2-normalised, not the caller's array (the
+    reference normalises a copy, here the rows are normalised after the upload); for L2
+    nothing is normalised.
 ``search_and_save`` keeps the file protocol (cath/search.py:29-53): for "Cosine" and
 "Euclidean", every ``*.npy`` in the data directory (fp16 files are cast to fp32) is
 searched, ``<stem>.<metric>-search-time.txt`` records the wall time of
@@ -26,13 +27,17 @@ _METRICS = (("Cosine", faiss.METRIC_INNER_PRODUCT), ("Euclidean", faiss.METRIC_L
 
 
 def search(embeddings: ndarray, hits: int = 10, metric=faiss.METRIC_INNER_PRODUCT) -> Tuple[ndarray, ndarray]:
-    vectors = embeddings
+    # One upload: the rows are added as they are, normalised in HBM (the reference normalises
+    # a private copy on the host, so the caller's array is left alone either way) and then
+    # serve as their own queries.  Same bits as normalize_L2 + add + search on the host arrays
+    # (tests/test_flat_gpu.py::test_search_self_equals_host_path).
+    index = faiss.IndexFlat(embeddings.shape[1], metric)
     if metric == faiss.METRIC_INNER_PRODUCT:
-        vectors = numpy.array(embeddings, dtype=numpy.float32, order="C", copy=True)
-        faiss.normalize_L2(vectors)
-    index = faiss.IndexFlat(vectors.shape[1], metric)
-    index.add(vectors)
-    scores, neighbours = index.search(vectors, hits + 1)
+        index.add(numpy.ascontiguousarray(embeddings))  # the reference's .copy() also makes it contiguous
+        index.normalize_rows()
+    else:
+        index.add(embeddings)
+    scores, neighbours = index.search_self(hits + 1)
     return neighbours[:, 1:], scores[:, 1:]
 
 

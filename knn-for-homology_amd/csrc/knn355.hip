@@ -1839,13 +1839,13 @@ extern "C" int knn_merge_keys_dev(int32_t device, int32_t metric, const uint64_t
     return 0;
 }
 
-extern "C" int knn_flat_search(knn_handle h, const float *q_host, int64_t nq, int64_t k, float *D_host,
-                               int64_t *I_host)
+// Search with results (and, unless q_host is null, queries) in host memory.  q_host == nullptr:
+// the queries are the index's own rows [self_row0, self_row0 + nq) -- already on the device and
+// padded, nothing to upload.  Caller holds h->mu.
+static int host_search(knn_index_s *h, const float *q_host, int64_t self_row0, int64_t nq, int64_t k, float *D_host,
+                       int64_t *I_host)
 {
-    int rc = check_search_args(h, q_host, nq, k, D_host, I_host);
-    if (rc) return rc;
-    if (nq == 0) return 0;
-    std::lock_guard<std::mutex> lk(h->mu);
+    int rc = 0;
     HIP_TRY(hipSetDevice(h->device));
     // Query batches bound the device workspace; 16384 queries keep >= 128 query tiles in flight.
     // Batches are pipelined: while batch b is scanned, a helper thread downloads the results of
@@ -1857,13 +1857,20 @@ extern "C" int knn_flat_search(knn_handle h, const float *q_host, int64_t nq, in
     DevBuf *qbuf[2] = {&h->ws_tmp2, &h->ws_tmp3}, *dbuf[2] = {&h->ws_D, &h->ws_D1}, *ibuf[2] = {&h->ws_I, &h->ws_I1};
     const int nslots = nbatches > 1 ? 2 : 1;
     for (int i = 0; i < nslots; i++)
-        if (qbuf[i]->ensure((size_t)bq * h->d * 4) || dbuf[i]->ensure((size_t)bq * k * 4) || ibuf[i]->ensure((size_t)bq * k * 8))
+        if ((q_host && qbuf[i]->ensure((size_t)bq * h->d * 4)) || dbuf[i]->ensure((size_t)bq * k * 4) || ibuf[i]->ensure((size_t)bq * k * 8))
             return set_err(KNN_ERR_HIP, "search: out of device memory");
+    // one batch of queries on the device: uploaded rows ([m][d]) or the index's own rows ([m][dp])
+    auto scan = [&](int slot, int64_t b0, int64_t m) -> int {
+        if (q_host)
+            return search_dev_impl(h, (const float *)qbuf[slot]->p, m, (int)k, (float *)dbuf[slot]->p, (int64_t *)ibuf[slot]->p, nullptr, 0, h->stream);
+        return search_keys_impl(h, h->xb + (size_t)(self_row0 + b0) * h->dp, m, (int)k, 0, nullptr, (float *)dbuf[slot]->p,
+                                (int64_t *)ibuf[slot]->p, h->stream);
+    };
     if (nbatches == 1) {
         // nothing to overlap with: one stream, no helper thread, no extra HSA queues (callers such
         // as cath/search.py build a fresh index per embedding file and search it once)
-        HIP_TRY(hipMemcpyAsync(qbuf[0]->p, q_host, (size_t)nq * h->d * 4, hipMemcpyHostToDevice, h->stream));
-        rc = search_dev_impl(h, (const float *)qbuf[0]->p, nq, (int)k, (float *)dbuf[0]->p, (int64_t *)ibuf[0]->p, nullptr, 0, h->stream);
+        if (q_host) HIP_TRY(hipMemcpyAsync(qbuf[0]->p, q_host, (size_t)nq * h->d * 4, hipMemcpyHostToDevice, h->stream));
+        rc = scan(0, 0, nq);
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(D_host, dbuf[0]->p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipMemcpyAsync(I_host, ibuf[0]->p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, h->stream));
@@ -1895,6 +1902,7 @@ extern "C" int knn_flat_search(knn_handle h, const float *q_host, int64_t nq, in
         if (dl[slot].t0 && hipEventElapsedTime(&ms, dl[slot].t0, dl[slot].t1) == hipSuccess) ms_total += ms;
     };
     auto upload = [&](int64_t b) -> hipError_t {
+        if (!q_host) return hipSuccess;
         const int slot = (int)(b & 1);
         const int64_t b0 = b * QB, m = std::min(QB, nq - b0);
         hipError_t e = hipMemcpyAsync(qbuf[slot]->p, q_host + b0 * h->d, (size_t)m * h->d * 4, hipMemcpyHostToDevice, h->stream_h2d);
@@ -1905,9 +1913,9 @@ extern "C" int knn_flat_search(knn_handle h, const float *q_host, int64_t nq, in
     for (int64_t b = 0; b < nbatches && e == hipSuccess && rc == 0; b++) {
         const int slot = (int)(b & 1);
         const int64_t b0 = b * QB, m = std::min(QB, nq - b0);
-        e = hipStreamWaitEvent(h->stream, h->ev_query[slot], 0);
+        if (q_host) e = hipStreamWaitEvent(h->stream, h->ev_query[slot], 0);
         if (e != hipSuccess) break;
-        rc = search_dev_impl(h, (const float *)qbuf[slot]->p, m, (int)k, (float *)dbuf[slot]->p, (int64_t *)ibuf[slot]->p, nullptr, 0, h->stream);
+        rc = scan(slot, b0, m);
         if (rc) break;
         e = hipEventRecord(h->ev_batch[slot], h->stream);
         if (e != hipSuccess) break;
@@ -1935,6 +1943,41 @@ extern "C" int knn_flat_search(knn_handle h, const float *q_host, int64_t nq, in
     if (dl_err != hipSuccess) return set_err(KNN_ERR_HIP, std::string("search: result download failed: ") + hipGetErrorString(dl_err));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->last_ms = ms_total;
+    return 0;
+}
+
+extern "C" int knn_flat_search(knn_handle h, const float *q_host, int64_t nq, int64_t k, float *D_host,
+                               int64_t *I_host)
+{
+    int rc = check_search_args(h, q_host, nq, k, D_host, I_host);
+    if (rc) return rc;
+    if (nq == 0) return 0;
+    std::lock_guard<std::mutex> lk(h->mu);
+    return host_search(h, q_host, 0, nq, k, D_host, I_host);
+}
+
+extern "C" int knn_flat_search_self(knn_handle h, int64_t row0, int64_t nrows, int64_t k, float *D_host, int64_t *I_host)
+{
+    if (!h) return set_err(KNN_ERR_INVALID, "search_self: null handle");
+    if (nrows == 0) return 0;
+    int rc = check_search_args(h, D_host, nrows, k, D_host, I_host);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (row0 < 0 || nrows < 0 || row0 + nrows > h->ntotal) return set_err(KNN_ERR_INVALID, "search_self: row range out of bounds");
+    return host_search(h, nullptr, row0, nrows, k, D_host, I_host);
+}
+
+extern "C" int knn_flat_normalize_rows(knn_handle h)
+{
+    if (!h) return set_err(KNN_ERR_INVALID, "normalize_rows: null handle");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (h->ntotal == 0) return 0;
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = normalize_dev_impl(h->xb, h->ntotal, h->d, h->dp, h->stream);
+    if (rc) return rc;
+    rc = norms_dev_impl(h->xb, h->ntotal, h->d, h->dp, h->yn, h->stream);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
     return 0;
 }
 

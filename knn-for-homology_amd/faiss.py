@@ -111,6 +111,23 @@ class IndexFlat(Index):
         return self.reconstruct_n(int(i), 1)[0]
 
     # -- knn355 extras (not in faiss) --
+    def search_self(self, k, row0=0, nrows=None):
+        """``index.search(x, k)`` for x = the index's own rows [row0, row0+nrows): the all-vs-all
+        the reference runs (cath/search.py:22-24), without uploading the queries again."""
+        k = int(k)
+        if k < 1:
+            raise AssertionError("k must be positive")
+        nrows = self.ntotal - row0 if nrows is None else int(nrows)
+        D = np.empty((nrows, k), np.float32)
+        I = np.empty((nrows, k), np.int64)
+        _lib.check(_lib.lib().knn_flat_search_self(self._h, int(row0), nrows, k, D.ctypes.data, I.ctypes.data))
+        return D, I
+
+    def normalize_rows(self):
+        """L2-normalises the stored rows in place on the device (``faiss.normalize_L2`` applied
+        to what was added, bit for bit, without the host round trip)."""
+        _lib.check(_lib.lib().knn_flat_normalize_rows(self._h))
+
     def set_tuning(self, query_tile=0, nchunks=0, flags=0):
         _lib.check(_lib.lib().knn_set_tuning(self._h, query_tile, nchunks, flags))
 

@@ -77,7 +77,11 @@ def main(argv: Optional[Sequence[str]] = None, data_dir: Optional[Path] = None, 
           f"Difference: {naturalsize(index_size - npy_size)}")
 
     started = time()
-    scores, hits = index.search(embeddings, k)
+    if index_mode == "flat":
+        # the queries are the rows just added (pfam/proteins_search.py:37,49): no second upload
+        scores, hits = index.search_self(k)
+    else:
+        scores, hits = index.search(embeddings, k)
     print(f"Search took {int(time() - started)}s")
     numpy.save(data_dir / f"full_sequences_{index_mode}_scores.npy", scores)
     numpy.save(data_dir / f"full_sequences_{index_mode}_hits.npy", hits)

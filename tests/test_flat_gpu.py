@@ -288,6 +288,36 @@ def test_result_independent_of_tiling(gpu_faiss):
             _assert_same(D, I, *ref)
 
 
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("n,d,k", [(3000, 200, 11), (20000, 64, 5), (700, 1024, 301)])
+def test_search_self_equals_host_path(gpu_faiss, oracle, n, d, k, metric):
+    """The one-upload all-vs-all (add, normalize_rows, search_self) returns the bits of the
+    reference's sequence normalize_L2(copy) / add / search(same array); 20000 rows cross the
+    16384-query batch boundary of the pipelined host search."""
+    rng = np.random.default_rng(n + d)
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    host = x.copy()
+    if metric == 0:
+        gpu_faiss.normalize_L2(host)
+    a = gpu_faiss.IndexFlat(d, metric)
+    a.add(host)
+    Dh, Ih = a.search(host, k)
+    b = gpu_faiss.IndexFlat(d, metric)
+    b.add(x)
+    if metric == 0:
+        b.normalize_rows()
+        assert np.array_equal(b.reconstruct_n(0, n).view(np.uint32), host.view(np.uint32))
+    Ds, Is = b.search_self(k)
+    _assert_same(Ds, Is, Dh, Ih)
+    D2, I2 = b.search_self(k, row0=n // 3, nrows=257)
+    _assert_same(D2, I2, Dh[n // 3:n // 3 + 257], Ih[n // 3:n // 3 + 257])
+    sample = rng.choice(n, 16, replace=False)
+    Do, Io = oracle.flat_search(host, host[sample], k, metric)
+    _assert_same(Ds[sample], Is[sample], Do, Io)
+    with pytest.raises(RuntimeError):
+        b.search_self(k, row0=n - 5, nrows=10)
+
+
 # ---- full-size configs: size-independent properties + sampled oracle rows ---------------
 def test_cath20_sized_all_vs_all(gpu_faiss, oracle):
     """BASELINE config 2: 14433 x 1024 all-vs-all, L2, k=300 (+ self)."""

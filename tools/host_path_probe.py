@@ -27,3 +27,6 @@ t0 = time.time(); idx.add(x); print(f"add: {time.time()-t0:.3f}s")
 for k in (100, 1000):
     t0 = time.time(); D, I = idx.search(x, k); t = time.time() - t0
     print(f"IndexFlat.search 200000 x 200000 k={k}: {t:.3f}s end-to-end -> {n/t:.0f} q/s", flush=True)
+    t0 = time.time(); D2, I2 = idx.search_self(k); t = time.time() - t0
+    assert (I2 == I).all()
+    print(f"IndexFlat.search_self 200000 k={k}: {t:.3f}s end-to-end -> {n/t:.0f} q/s", flush=True)
