@@ -13,7 +13,8 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libknn355.so")
+# KNN355_LIB: another build of the same library (timing-ablation builds, tools/ only)
+LIB_PATH = os.environ.get("KNN355_LIB") or os.path.join(_HERE, "libknn355.so")
 
 _lib = None
 

@@ -819,9 +819,15 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
                 for (int kt = 0; kt + 1 < KT; kt++) {
                     char *cur = (kt & 1) ? stage1 : stage0;
                     char *nxt = (kt & 1) ? stage0 : stage1;
+#ifndef KNN355_ABLATE_BARRIER // timing experiments only (wrong results): no K-step barrier / no staging
                     __syncthreads(); // stage kt landed (vmcnt(0) + barrier); buffer nxt is free
+#endif
                     const int koff = (kt + 1) * 32;
+#ifdef KNN355_ABLATE_DMA
+                    compute(cur, no_dma, nd_none{});
+#else
                     compute(cur, [&](int n) { stage_issue<true>(tsrc[n] + koff, nxt + lds_off[n], lane, sreg[n]); }, nd_all{});
+#endif
                 }
                 __syncthreads();
                 compute(((KT - 1) & 1) ? stage1 : stage0, no_dma, nd_none{});
