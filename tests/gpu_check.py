@@ -7,7 +7,7 @@ from pathlib import Path
 
 import numpy as np
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent  # repo root (this script lives in tests/: it uses the oracle)
 sys.path.insert(0, str(ROOT))
 from knn_for_homology_amd import faiss, _lib  # noqa: E402
 from oracle import knn_oracle as ko  # noqa: E402

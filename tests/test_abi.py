@@ -64,6 +64,9 @@ def test_product_never_imports_oracle():
     for f in (pkg / "csrc").glob("*"):
         if f.suffix in (".hip", ".cpp", ".h"):
             assert "knn_oracle" not in f.read_text().replace("oracle/knn_oracle.c", "")
+    # developer tools are not allowed to use it either: only tests/, smoke() and bench.py's cpu_baseline
+    for f in (ROOT / "tools").rglob("*.py"):
+        assert "oracle" not in f.read_text(), f"{f} mentions the oracle"
 
 
 def test_entry_points_importable():
