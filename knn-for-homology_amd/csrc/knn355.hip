@@ -259,6 +259,11 @@ __device__ __attribute__((noinline)) int wave_select(LD load, int n, int k, int 
                                                      uint32_t *hist)
 {
     static_assert(R <= 64, "at most 4096 keys per wave");
+    // wave-uniform by contract; arguments of a non-inlined function arrive in VGPRs and the
+    // compiler would otherwise run the search loop on lane masks
+    n = __builtin_amdgcn_readfirstlane(n);
+    k = __builtin_amdgcn_readfirstlane(k);
+    kmax = __builtin_amdgcn_readfirstlane(kmax);
     uint32_t hi[R], lo[R];
     uint32_t mn = 0xFFFFFFFFu, mx = 0u;
 #pragma unroll
@@ -348,24 +353,44 @@ __device__ __attribute__((noinline)) int wave_select(LD load, int n, int k, int 
             prefix |= (uint32_t)bin << shift;
             shift -= 8;
         }
-    } else if (mn != mx) {
-        const int b0 = 31 - __clz((int)(mn ^ mx));
-        uint32_t P = (b0 == 31) ? 0u : (mx & ~((2u << b0) - 1u));
-        bool done = false;
-        for (int bit = b0; bit >= 0; --bit) {
-            const uint32_t Pt = P | (1u << bit);
-            const int c = count_lt(Pt);
-            if (c <= k - 1) {
-                P = Pt;
+    } else if (mn != mx && cnt > kmax) {
+        // Bracket search on the score word for an X with k <= #(keys < X) <= kmax.  f(X) = #(keys < X)
+        // is monotone, f(mn) = 0 < k and f(mx + 1) = cnt > kmax.  Probes alternate between linear
+        // interpolation of the target rank inside the bracket (scores between mn and mx are close
+        // to evenly spread in the order-preserving integer image, so 3-5 probes usually do where
+        // an MSB-first bit search spends 15-25, most of them on the empty leading bits) and
+        // bisection (so the bracket at least halves every second probe).  A bracket of width one
+        // means the k-th key ties with its neighbours on the score word: T is that word exactly and
+        // the id tie-break below finishes the job.
+        uint32_t lo_x = mn, hi_x = mx + 1u; // mx < 0xFFFFFFFF here (padding was split off above)
+        int f_lo = 0, f_hi = cnt;
+        const float target = 0.5f * (float)(k + kmax);
+        bool interpolate = true, done = false;
+        while (hi_x - lo_x > 1u) {
+            uint32_t X;
+            if (interpolate)
+                X = lo_x + (uint32_t)((float)(hi_x - lo_x) * ((target - (float)f_lo) / (float)(f_hi - f_lo)));
+            else
+                X = lo_x + ((hi_x - lo_x) >> 1);
+            X = max(lo_x + 1u, min(X, hi_x - 1u));
+            interpolate = !interpolate;
+            const int c = count_lt(X);
+            if (c < k) {
+                lo_x = X;
+                f_lo = c;
+            } else if (c > kmax) {
+                hi_x = X;
+                f_hi = c;
             } else {
-                T = Pt - 1u;
+                T = X - 1u;
                 cnt = c;
-                if (c <= kmax) { done = true; break; }
+                done = true;
+                break;
             }
         }
-        if (!done) { // P is the exact k-th smallest score word
-            T = P;
-            cnt = P == 0xFFFFFFFFu ? n : count_lt(P + 1u);
+        if (!done) { // lo_x is the exact k-th smallest score word
+            T = lo_x;
+            cnt = f_hi;
         }
     }
     uint32_t Q = 0xFFFFFFFFu;
