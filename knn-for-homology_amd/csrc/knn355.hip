@@ -968,22 +968,40 @@ __global__ __launch_bounds__(256) void merge_select_kernel(const uint64_t *__res
         const int fill_to = final_round ? P : k;
         for (int i = have + lane; i < fill_to; i += 64) dst[i] = KEY_PAD;
     }
-    if (!final_round) return;
-    __syncthreads();
-    // every wave sorts its own P keys; identical control flow in all four waves
+    if (!final_round || !active) return;
+    // This wave sorts its own P keys in LDS.  One wave's LDS operations complete in order, so a
+    // wave-scope fence between the stages is all the synchronisation there is (no workgroup
+    // barrier: the four waves are independent).  Four compare-exchanges per lane are in flight at
+    // a time: the loads of a group are issued together instead of one dependent round trip per pair.
+    // (The keys arrived through generic-pointer stores, which do not take the DS path: a
+    // workgroup-scope fence drains them before the first DS read.)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    const int half = P >> 1;
     for (int k2 = 2; k2 <= P; k2 <<= 1) {
         for (int j = k2 >> 1; j > 0; j >>= 1) {
-            for (int i = lane; i < (P >> 1); i += 64) {
-                const int a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
-                const int b = a + j;
-                const bool up = (a & k2) == 0;
-                const uint64_t x = sb[a], y = sb[b];
-                if ((x > y) == up) { sb[a] = y; sb[b] = x; }
+            for (int base = 0; base < half; base += 256) {
+                int a[4];
+                uint64_t x[4], y[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i = base + u * 64 + lane;
+                    a[u] = i < half ? (((i & ~(j - 1)) << 1) | (i & (j - 1))) : -1;
+                    if (a[u] >= 0) {
+                        x[u] = sb[a[u]];
+                        y[u] = sb[a[u] + j];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (a[u] >= 0 && (x[u] > y[u]) == ((a[u] & k2) == 0)) {
+                        sb[a[u]] = y[u];
+                        sb[a[u] + j] = x[u];
+                    }
+                }
             }
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
     }
-    if (!active) return;
     if (out_keys)
         for (int i = k + lane; i < out_key_fill; i += 64) out_keys[(size_t)q * out_key_stride + i] = KEY_PAD;
     for (int i = lane; i < k; i += 64) {
