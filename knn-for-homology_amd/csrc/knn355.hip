@@ -977,31 +977,36 @@ __global__ __launch_bounds__(256) void merge_select_kernel(const uint64_t *__res
     // workgroup-scope fence drains them before the first DS read.)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     const int half = P >> 1;
-    for (int k2 = 2; k2 <= P; k2 <<= 1) {
-        for (int j = k2 >> 1; j > 0; j >>= 1) {
-            for (int base = 0; base < half; base += 256) {
-                int a[4];
-                uint64_t x[4], y[4];
+    // NP compare-exchanges per lane and pass, no per-pair guards (half is 32, or a multiple of 64 * NP)
+    auto sort_with = [&](auto np_tag) {
+        constexpr int NP = decltype(np_tag)::value;
+        for (int k2 = 2; k2 <= P; k2 <<= 1) {
+            for (int j = k2 >> 1; j > 0; j >>= 1) {
+                for (int base = 0; base < half; base += 64 * NP) {
+                    int a[NP];
+                    uint64_t x[NP], y[NP];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int i = base + u * 64 + lane;
-                    a[u] = i < half ? (((i & ~(j - 1)) << 1) | (i & (j - 1))) : -1;
-                    if (a[u] >= 0) {
+                    for (int u = 0; u < NP; u++) {
+                        const int i = min(base + u * 64 + lane, half - 1); // only P = 64 clamps (lanes 32..63 idle)
+                        a[u] = ((i & ~(j - 1)) << 1) | (i & (j - 1));
                         x[u] = sb[a[u]];
                         y[u] = sb[a[u] + j];
                     }
-                }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    if (a[u] >= 0 && (x[u] > y[u]) == ((a[u] & k2) == 0)) {
-                        sb[a[u]] = y[u];
-                        sb[a[u] + j] = x[u];
+                    for (int u = 0; u < NP; u++) {
+                        if (base + u * 64 + lane < half && (x[u] > y[u]) == ((a[u] & k2) == 0)) {
+                            sb[a[u]] = y[u];
+                            sb[a[u] + j] = x[u];
+                        }
                     }
                 }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
-    }
+    };
+    if (half <= 64) sort_with(std::integral_constant<int, 1>{});
+    else if (half == 128) sort_with(std::integral_constant<int, 2>{});
+    else sort_with(std::integral_constant<int, 4>{});
     if (out_keys)
         for (int i = k + lane; i < out_key_fill; i += 64) out_keys[(size_t)q * out_key_stride + i] = KEY_PAD;
     for (int i = lane; i < k; i += 64) {
