@@ -675,6 +675,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
     L.s_thr = (float *)(smem + lds_main);
     L.s_cnt = (int *)(L.s_thr + QT);
     L.s_need = L.s_cnt + QT;
+    float *s_yn = (float *)(L.s_need + 4); // [DT] squared norms of the current tile's rows (L2 only)
     L.lists = p.lists + (size_t)blockIdx.x * QT * p.cap;
     L.gthr = p.gthr + (size_t)qtile * QT;
     L.cap = p.cap;
@@ -728,6 +729,12 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
             } else {
                 tsrc[n] = srcp[n];
             }
+        }
+        if constexpr (L2) {
+            // the tile's squared norms: one coalesced load per thread now, LDS reads in the epilogue
+            // (visible after the K loop's barriers) instead of 16 * TM * TN scattered global loads
+            // per lane at the end of the tile
+            if (tid < DT) s_yn[tid] = p.yn[view_row(min(row0 + tid, p.nb - 1), p.row_mul)];
         }
         // One K step of MFMA work from buffer `cur`.  `dma(n)` (n < NI) issues this wave's n-th
         // staging instruction of the NEXT K step; the NI of them are spread between the MFMAs so
@@ -891,7 +898,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
                     const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
                     float v;
                     if constexpr (L2) {
-                        float ynr = p.yn[view_row(min(row, p.nb - 1), p.row_mul)];
+                        float ynr = s_yn[(wm * TM + a) * 32 + 4 * lh + (r & 3) + 8 * (r >> 2)];
                         float t = xnq + ynr;
                         v = __builtin_fmaf(-2.0f, acc[a][b][r], t);
                         v = v < 0.0f ? 0.0f : v;
@@ -1689,7 +1696,7 @@ static void make_plan(const knn_index_s *h, int64_t nb, int64_t nq, int k, bool 
     pl.chunk_rows = tiles_per * pl.dt;
     pl.nchunks = (int)((nb + pl.chunk_rows - 1) / pl.chunk_rows);
     pl.grid = pl.nqtiles * pl.nchunks;
-    pl.lds = std::max((size_t)2 * (pl.dt + pl.qt) * 128, (size_t)pl.cap * 8) + (size_t)qt * 8 + 16;
+    pl.lds = std::max((size_t)2 * (pl.dt + pl.qt) * 128, (size_t)pl.cap * 8) + (size_t)qt * 8 + 16 + (size_t)pl.dt * 4;
 }
 
 // Seed stride of a view with nb rows: a power of two s such that the sample (every s-th 8-row block)
