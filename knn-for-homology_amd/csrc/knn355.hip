@@ -1244,10 +1244,6 @@ struct knn_index_s {
     float *yn = nullptr; // [cap_rows + pad]
     size_t xb_bytes = 0, yn_bytes = 0; // allocation sizes (may exceed the row capacity: pooled)
     hipStream_t stream = nullptr;
-    // host-buffer searches: query upload and result download run beside the scan of the
-    // neighbouring batch (own streams, two sets of staging buffers, see knn_flat_search)
-    hipStream_t stream_h2d = nullptr, stream_d2h = nullptr;
-    hipEvent_t ev_query[2] = {nullptr, nullptr}, ev_batch[2] = {nullptr, nullptr};
     hipEvent_t ev0 = nullptr, ev1 = nullptr; // the pair of the most recent scan launch
     static const int RING = 64;
     hipEvent_t ring0[RING] = {nullptr}, ring1[RING] = {nullptr};
@@ -1408,12 +1404,6 @@ extern "C" void knn_free(knn_handle h)
         DevBuf *bufs[] = {&h->ws_q, &h->ws_qn, &h->ws_lists, &h->ws_gthr, &h->ws_partial, &h->ws_partial2,
                           &h->ws_keys, &h->ws_D, &h->ws_I, &h->ws_tmp, &h->ws_tmp2, &h->ws_D1, &h->ws_I1, &h->ws_tmp3};
         for (DevBuf *b : bufs) b->release();
-        for (int i = 0; i < 2; i++) {
-            if (h->ev_query[i]) (void)hipEventDestroy(h->ev_query[i]);
-            if (h->ev_batch[i]) (void)hipEventDestroy(h->ev_batch[i]);
-        }
-        if (h->stream_h2d) (void)hipStreamDestroy(h->stream_h2d);
-        if (h->stream_d2h) (void)hipStreamDestroy(h->stream_d2h);
         for (DevBuf &b : h->ws_level) b.release();
         for (int i = 0; i < knn_index_s::RING; i++) {
             if (h->ring0[i]) (void)hipEventDestroy(h->ring0[i]);
@@ -1900,6 +1890,17 @@ extern "C" int knn_merge_keys_dev(int32_t device, int32_t metric, const uint64_t
     return 0;
 }
 
+// Copy streams of the pipelined host search: one set per device for the whole process, created on
+// first use (a HIP stream costs milliseconds to create and callers such as cath/search.py build a
+// fresh index per file).  Whoever holds `mu` pipelines; a concurrent host search on the same
+// device simply runs its batches one after the other on its own stream.
+struct CopyPipes {
+    std::mutex mu;
+    hipStream_t h2d = nullptr, d2h = nullptr;
+    hipEvent_t ev_query[2] = {nullptr, nullptr}, ev_batch[2] = {nullptr, nullptr};
+};
+static CopyPipes g_pipes[64];
+
 // Search with results (and, unless q_host is null, queries) in host memory.  q_host == nullptr:
 // the queries are the index's own rows [self_row0, self_row0 + nq) -- already on the device and
 // padded, nothing to upload.  Caller holds h->mu.
@@ -1912,7 +1913,12 @@ static int host_search(knn_index_s *h, const float *q_host, int64_t self_row0, i
     // Batches are pipelined: while batch b is scanned, a helper thread downloads the results of
     // batch b-1 (pageable host memory: the copy blocks its caller) and this thread uploads the
     // queries of batch b+1, each on its own stream with its own staging buffers.
-    const int64_t QB = 16384;
+    int64_t QB = 16384;
+    // A single batch with a large result (CATH20-sized all-vs-all with 300 hits: 52 MB, as long on
+    // the wire as the scan takes) is split in up to four so that its download overlaps too; small
+    // results are not worth the extra launches and the extra streams of the pipelined path.
+    if (nq <= QB && (size_t)nq * k * 12 >= ((size_t)24 << 20) && nq >= 4096)
+        QB = std::max<int64_t>(2048, ((nq + 3) / 4 + 127) / 128 * 128);
     const int64_t bq = std::min(nq, QB);
     const int64_t nbatches = (nq + QB - 1) / QB;
     DevBuf *qbuf[2] = {&h->ws_tmp2, &h->ws_tmp3}, *dbuf[2] = {&h->ws_D, &h->ws_D1}, *ibuf[2] = {&h->ws_I, &h->ws_I1};
@@ -1927,25 +1933,35 @@ static int host_search(knn_index_s *h, const float *q_host, int64_t self_row0, i
         return search_keys_impl(h, h->xb + (size_t)(self_row0 + b0) * h->dp, m, (int)k, 0, nullptr, (float *)dbuf[slot]->p,
                                 (int64_t *)ibuf[slot]->p, h->stream);
     };
-    if (nbatches == 1) {
-        // nothing to overlap with: one stream, no helper thread, no extra HSA queues (callers such
-        // as cath/search.py build a fresh index per embedding file and search it once)
-        if (q_host) HIP_TRY(hipMemcpyAsync(qbuf[0]->p, q_host, (size_t)nq * h->d * 4, hipMemcpyHostToDevice, h->stream));
-        rc = scan(0, 0, nq);
-        if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(D_host, dbuf[0]->p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipMemcpyAsync(I_host, ibuf[0]->p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, h->stream));
+    // plain form: one batch at a time on the handle's stream (nothing to overlap with, or the
+    // device's copy streams are taken)
+    auto plain = [&](int64_t b0, int64_t m) -> int {
+        if (q_host) HIP_TRY(hipMemcpyAsync(qbuf[0]->p, q_host + b0 * h->d, (size_t)m * h->d * 4, hipMemcpyHostToDevice, h->stream));
+        int r = scan(0, b0, m);
+        if (r) return r;
+        HIP_TRY(hipMemcpyAsync(D_host + b0 * k, dbuf[0]->p, (size_t)m * k * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(I_host + b0 * k, ibuf[0]->p, (size_t)m * k * 8, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
         float ms = 0.f;
-        h->last_ms = (h->ntotal > 0 && h->ev0 && hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) ? ms : 0.f;
+        if (h->ntotal > 0 && h->ev0 && hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->last_ms += ms;
+        return 0;
+    };
+    CopyPipes &cp = g_pipes[h->device & 63];
+    std::unique_lock<std::mutex> pipes(cp.mu, std::defer_lock);
+    if (nbatches == 1 || !pipes.try_lock()) {
+        h->last_ms = 0.f;
+        for (int64_t b0 = 0; b0 < nq; b0 += QB) {
+            rc = plain(b0, std::min(QB, nq - b0));
+            if (rc) return rc;
+        }
         return 0;
     }
-    if (!h->stream_h2d) {
-        HIP_TRY(hipStreamCreateWithFlags(&h->stream_h2d, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&h->stream_d2h, hipStreamNonBlocking));
+    if (!cp.h2d) {
+        HIP_TRY(hipStreamCreateWithFlags(&cp.h2d, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&cp.d2h, hipStreamNonBlocking));
         for (int i = 0; i < 2; i++) {
-            HIP_TRY(hipEventCreateWithFlags(&h->ev_query[i], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&h->ev_batch[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&cp.ev_query[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&cp.ev_batch[i], hipEventDisableTiming));
         }
     }
     struct Download {
@@ -1966,29 +1982,30 @@ static int host_search(knn_index_s *h, const float *q_host, int64_t self_row0, i
         if (!q_host) return hipSuccess;
         const int slot = (int)(b & 1);
         const int64_t b0 = b * QB, m = std::min(QB, nq - b0);
-        hipError_t e = hipMemcpyAsync(qbuf[slot]->p, q_host + b0 * h->d, (size_t)m * h->d * 4, hipMemcpyHostToDevice, h->stream_h2d);
-        if (e == hipSuccess) e = hipEventRecord(h->ev_query[slot], h->stream_h2d);
+        hipError_t e = hipMemcpyAsync(qbuf[slot]->p, q_host + b0 * h->d, (size_t)m * h->d * 4, hipMemcpyHostToDevice, cp.h2d);
+        if (e == hipSuccess) e = hipEventRecord(cp.ev_query[slot], cp.h2d);
         return e;
     };
     hipError_t e = upload(0);
     for (int64_t b = 0; b < nbatches && e == hipSuccess && rc == 0; b++) {
         const int slot = (int)(b & 1);
         const int64_t b0 = b * QB, m = std::min(QB, nq - b0);
-        if (q_host) e = hipStreamWaitEvent(h->stream, h->ev_query[slot], 0);
+        if (q_host) e = hipStreamWaitEvent(h->stream, cp.ev_query[slot], 0);
         if (e != hipSuccess) break;
         rc = scan(slot, b0, m);
         if (rc) break;
-        e = hipEventRecord(h->ev_batch[slot], h->stream);
+        e = hipEventRecord(cp.ev_batch[slot], h->stream);
         if (e != hipSuccess) break;
         dl[slot].t0 = h->ntotal > 0 ? h->ev0 : nullptr;
         dl[slot].t1 = h->ev1;
         dl[slot].err = hipSuccess;
+        CopyPipes *cpp = &cp;
         dl[slot].th = std::thread([=, &dl]() {
             hipError_t r = hipSetDevice(h->device);
-            if (r == hipSuccess) r = hipEventSynchronize(h->ev_batch[slot]);
-            if (r == hipSuccess) r = hipMemcpyAsync(D_host + b0 * k, dbuf[slot]->p, (size_t)m * k * 4, hipMemcpyDeviceToHost, h->stream_d2h);
-            if (r == hipSuccess) r = hipMemcpyAsync(I_host + b0 * k, ibuf[slot]->p, (size_t)m * k * 8, hipMemcpyDeviceToHost, h->stream_d2h);
-            if (r == hipSuccess) r = hipStreamSynchronize(h->stream_d2h);
+            if (r == hipSuccess) r = hipEventSynchronize(cpp->ev_batch[slot]);
+            if (r == hipSuccess) r = hipMemcpyAsync(D_host + b0 * k, dbuf[slot]->p, (size_t)m * k * 4, hipMemcpyDeviceToHost, cpp->d2h);
+            if (r == hipSuccess) r = hipMemcpyAsync(I_host + b0 * k, ibuf[slot]->p, (size_t)m * k * 8, hipMemcpyDeviceToHost, cpp->d2h);
+            if (r == hipSuccess) r = hipStreamSynchronize(cpp->d2h);
             dl[slot].err = r;
         });
         if (b + 1 < nbatches) {
