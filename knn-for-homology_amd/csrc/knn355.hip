@@ -460,12 +460,19 @@ __device__ __forceinline__ int wave_select_dispatch(int R, LD load, int n, int k
 // The merge kernel may also use 64 keys per lane (4096 keys): it is its own kernel, so the
 // 250 registers of that variant do not cost the scan kernels their second wave per SIMD
 // (a non-inlined callee's registers count for every kernel that can reach it).
-template <typename LD>
-__device__ __forceinline__ int wave_select_dispatch64(int R, LD load, int n, int k, int kmax, int lane,
-                                                      uint32_t *thr_ord, uint64_t *dst, uint32_t *hist)
+template <int RMAX, typename LD>
+__device__ __forceinline__ int wave_select_dispatch_max(int R, LD load, int n, int k, int kmax, int lane,
+                                                        uint32_t *thr_ord, uint64_t *dst, uint32_t *hist)
 {
-    if (R <= 32) return wave_select_dispatch(R, load, n, k, kmax, lane, thr_ord, dst, hist);
-    return wave_select<64, LD>(load, n, k, kmax, lane, thr_ord, dst, hist);
+    if constexpr (RMAX <= 16) {
+        if (R <= 8) return wave_select<8, LD>(load, n, k, kmax, lane, thr_ord, dst, hist);
+        return wave_select<16, LD>(load, n, k, kmax, lane, thr_ord, dst, hist);
+    } else if constexpr (RMAX <= 32) {
+        return wave_select_dispatch(R, load, n, k, kmax, lane, thr_ord, dst, hist);
+    } else {
+        if (R <= 32) return wave_select_dispatch(R, load, n, k, kmax, lane, thr_ord, dst, hist);
+        return wave_select<64, LD>(load, n, k, kmax, lane, thr_ord, dst, hist);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -937,7 +944,10 @@ __global__ void seed_thresholds_kernel(const uint64_t *__restrict__ seed_keys, i
 // (out_keys [nq][Lout][k], more rounds follow) or -- last round, Lout == 1 --
 // sorts them in LDS and emits the final D / I (or sorted keys).
 // ---------------------------------------------------------------------------
-template <bool LISTMAJOR>
+// RMAX: most keys per lane any wave of this launch holds (16, 32 or 64): the register count of the
+// instantiation, hence how many waves share a SIMD -- merges of many queries are latency-bound and
+// live on that.
+template <bool LISTMAJOR, int RMAX>
 __global__ __launch_bounds__(256) void merge_select_kernel(const uint64_t *__restrict__ in, int L, int kin, int k,
                                                            int64_t nq, int G, int Lout, uint64_t *__restrict__ out_keys,
                                                            int64_t out_key_stride, int out_key_fill, int final_round,
@@ -963,9 +973,9 @@ __global__ __launch_bounds__(256) void merge_select_kernel(const uint64_t *__res
             uint32_t T;
             const int R = (n + 63) >> 6;
             if constexpr (LISTMAJOR)
-                have = wave_select_dispatch64(R, LoadListMajor{in, nq, q, kin, l0}, n, k, k, lane, &T, dst, hist);
+                have = wave_select_dispatch_max<RMAX>(R, LoadListMajor{in, nq, q, kin, l0}, n, k, k, lane, &T, dst, hist);
             else
-                have = wave_select_dispatch64(R, LoadContig{in + ((size_t)q * L + l0) * kin}, n, k, k, lane, &T, dst, hist);
+                have = wave_select_dispatch_max<RMAX>(R, LoadContig{in + ((size_t)q * L + l0) * kin}, n, k, k, lane, &T, dst, hist);
         } else {
             for (int i = lane; i < n; i += 64) {
                 if constexpr (LISTMAJOR) dst[i] = LoadListMajor{in, nq, q, kin, l0}(i);
@@ -1588,12 +1598,26 @@ static int run_merge(const uint64_t *in, int L, int kin, int k, int64_t nq, bool
         if (wave_path) {
             const unsigned grid = (unsigned)((items + 3) / 4);
             const size_t lds = final_round ? lds_final : 0;
-            if (lm)
-                hipLaunchKernelGGL(merge_select_kernel<true>, dim3(grid), dim3(256), lds, s, in, L, kin, k, nq, G, Lout, out,
-                                   final_round ? keys_out_stride : (int64_t)0, keys_out_fill, final_round ? 1 : 0, metric, D, I);
-            else
-                hipLaunchKernelGGL(merge_select_kernel<false>, dim3(grid), dim3(256), lds, s, in, L, kin, k, nq, G, Lout, out,
-                                   final_round ? keys_out_stride : (int64_t)0, keys_out_fill, final_round ? 1 : 0, metric, D, I);
+            const int rneed = (std::min(L, G) * kin + 63) / 64; // keys per lane of the fullest wave
+            auto launch = [&](auto lm_tag, auto r_tag) {
+                hipLaunchKernelGGL((merge_select_kernel<decltype(lm_tag)::value, decltype(r_tag)::value>), dim3(grid), dim3(256), lds, s, in, L,
+                                   kin, k, nq, G, Lout, out, final_round ? keys_out_stride : (int64_t)0, keys_out_fill,
+                                   final_round ? 1 : 0, metric, D, I);
+            };
+            using T_ = std::true_type;
+            using F_ = std::false_type;
+            using R16 = std::integral_constant<int, 16>;
+            using R32 = std::integral_constant<int, 32>;
+            using R64 = std::integral_constant<int, 64>;
+            if (lm) {
+                if (rneed <= 16) launch(T_{}, R16{});
+                else if (rneed <= 32) launch(T_{}, R32{});
+                else launch(T_{}, R64{});
+            } else {
+                if (rneed <= 16) launch(F_{}, R16{});
+                else if (rneed <= 32) launch(F_{}, R32{});
+                else launch(F_{}, R64{});
+            }
         } else {
             const size_t lds = (size_t)next_pow2_host(std::min(L, G) * kin) * 8;
             if (lm) {
