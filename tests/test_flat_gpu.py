@@ -271,6 +271,28 @@ def test_seeded_search_matches_oracle(gpu_faiss, oracle, metric):
     _assert_same(*idx.search(q, 50), *oracle.flat_search(xs, q, 50, metric))
 
 
+@pytest.mark.parametrize("nb", [8193, 8199, 40003, 65535, 65543])
+def test_seed_sample_blocks_with_ragged_tail(gpu_faiss, oracle, nb):
+    """The seed sample is every s-th block of 8 rows; a database that does not end on a block
+    (or whose last sample block is cut short) must still be searched exactly, every row counted
+    once: queries are planted rows, including the very last ones."""
+    rng = np.random.default_rng(nb)
+    d, k = 96, 37
+    xb = rng.standard_normal((nb, d), dtype=np.float32)
+    planted = np.array([0, 7, 8, nb - 9, nb - 8, nb - 2, nb - 1])
+    xq = np.concatenate([xb[planted], rng.standard_normal((9, d), dtype=np.float32)])
+    for metric in (0, 1):
+        Do, Io = oracle.flat_search(xb, xq, k, metric)
+        for flags in (16, 0):
+            idx = gpu_faiss.IndexFlat(d, metric)
+            idx.set_tuning(0, 0, flags)
+            idx.add(xb)
+            D, I = idx.search(xq, k)
+            _assert_same(D, I, Do, Io)
+            if metric == 1:
+                assert (I[:len(planted), 0] == planted).all() and (D[:len(planted), 0] == 0).all()
+
+
 def test_result_independent_of_tiling(gpu_faiss):
     """The same search under every query-tile / chunk split returns identical bits."""
     rng = np.random.default_rng(8)
