@@ -226,6 +226,17 @@ def cpu_baseline(sample_rows, q_host, k, nb_total, D_gpu, I_gpu, index):
         t_used += time.perf_counter() - t0
         reps += 1
     t_pass = t_used / reps
+    # and on one thread (the reference's own note on its flat search is "single core", pfam/slices/slices_search.py:10)
+    single = None
+    try:
+        from threadpoolctl import threadpool_limits as _limits
+        with _limits(limits=1, user_api="blas"):
+            t0 = time.perf_counter()
+            ko.faiss_flat_blas_restated(sample_rows[: max(1, S // 8)], q_host, k, ko.METRIC_INNER_PRODUCT, bs_y=8192)
+            t1 = (time.perf_counter() - t0) * 8.0
+        single = nq / (t1 * nb_total / S)
+    except Exception:
+        pass
     # same sample on the GPU: neighbours must agree (recall of the exact flat path)
     from knn_for_homology_amd import faiss
     sub = faiss.IndexFlat(sample_rows.shape[1], faiss.METRIC_INNER_PRODUCT)
@@ -238,7 +249,7 @@ def cpu_baseline(sample_rows, q_host, k, nb_total, D_gpu, I_gpu, index):
             "sample": f"numpy/OpenBLAS restatement of FAISS 1.7.2 knn_inner_product_blas (sgemm blocks of 4096 "
                       f"queries x 8192 rows + per-row top-k) on the first {S} of {nb_total} database rows, {nq} queries, {reps} passes of "
                       f"{t_pass:.3f}s; value extrapolates linearly to the full database",
-            "seconds_per_pass_on_sample": t_pass, "gpu_recall_at_k_on_sample": recall}
+            "seconds_per_pass_on_sample": t_pass, "gpu_recall_at_k_on_sample": recall, "single_thread_value": single}
 
 
 def batch_config(dev, L, _lib, faiss):
