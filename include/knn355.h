@@ -93,6 +93,14 @@ int knn_flat_search_dev(knn_handle h, const float *q_dev, int64_t nq, int64_t k,
 int knn_flat_search_self(knn_handle h, int64_t row0, int64_t nrows, int64_t k, float *D_host,
                          int64_t *I_host);
 int knn_flat_normalize_rows(knn_handle h);
+/* A second handle on the same device-resident rows with its own stream and scratch
+ * memory (read-only: add/reset/reserve/normalize_rows fail on it; it sees the rows present
+ * when it was made and must be freed before its parent).  Two searches on a handle and
+ * its view overlap on the GPU -- the small launches at either end of one search (seed
+ * sample, merges, the multi-GPU all-gather) hide behind the other one's scan.  FAISS's
+ * GPU flat index does the same with two streams; the reference's CPU path has no
+ * equivalent (seqvec_search/main.py:45 index.search is one blocking call). */
+int knn_flat_view(knn_handle parent, knn_handle *out);
 /* per-shard result as packed sortable keys (uint64: order-preserving score
  * bits << 32 | id_base + local row), k per query, ascending = best first,
  * padded with UINT64_MAX.  This is what ranks exchange (RCCL all-gather). */

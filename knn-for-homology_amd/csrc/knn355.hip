@@ -1250,6 +1250,7 @@ struct knn_index_s {
     int d = 0, dp = 0, metric = 0, device = 0;
     int num_cus = 256;
     int64_t ntotal = 0, cap_rows = 0;
+    bool is_view = false; // shares another handle's database (knn_flat_view): read-only, frees nothing of it
     float *xb = nullptr; // [cap_rows][dp]
     float *yn = nullptr; // [cap_rows + pad]
     size_t xb_bytes = 0, yn_bytes = 0; // allocation sizes (may exceed the row capacity: pooled)
@@ -1386,6 +1387,30 @@ extern "C" int knn_flat_create(int32_t d, int32_t metric, knn_handle *out)
     return 0;
 }
 
+extern "C" int knn_flat_view(knn_handle parent, knn_handle *out)
+{
+    if (!parent || !out) return set_err(KNN_ERR_INVALID, "flat_view: null argument");
+    std::lock_guard<std::mutex> lk(parent->mu);
+    HIP_TRY(hipSetDevice(parent->device));
+    knn_index_s *h = new knn_index_s();
+    h->d = parent->d;
+    h->dp = parent->dp;
+    h->metric = parent->metric;
+    h->device = parent->device;
+    h->num_cus = parent->num_cus;
+    h->is_view = true;
+    h->xb = parent->xb;
+    h->yn = parent->yn;
+    h->ntotal = parent->ntotal;
+    h->cap_rows = parent->ntotal;
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return set_err(KNN_ERR_HIP, "flat_view: stream creation failed");
+    }
+    *out = h;
+    return 0;
+}
+
 // database storage goes through the same pool as the scratch buffers
 static void *pool_alloc(size_t bytes, int device, size_t *got)
 {
@@ -1398,8 +1423,8 @@ static void *pool_alloc(size_t bytes, int device, size_t *got)
 
 static void free_index_buffers(knn_index_s *h)
 {
-    if (h->xb) g_pool.give(h->xb, h->xb_bytes, h->device);
-    if (h->yn) g_pool.give(h->yn, h->yn_bytes, h->device);
+    if (h->xb && !h->is_view) g_pool.give(h->xb, h->xb_bytes, h->device);
+    if (h->yn && !h->is_view) g_pool.give(h->yn, h->yn_bytes, h->device);
     h->xb = nullptr;
     h->yn = nullptr;
     h->ntotal = 0;
@@ -1433,6 +1458,7 @@ extern "C" int knn_reset(knn_handle h)
 {
     if (!h) return set_err(KNN_ERR_INVALID, "reset: null handle");
     std::lock_guard<std::mutex> lk(h->mu);
+    if (h->is_view) return set_err(KNN_ERR_INVALID, "reset: a view is read-only");
     HIP_TRY(hipSetDevice(h->device));
     free_index_buffers(h);
     return 0;
@@ -1497,6 +1523,7 @@ extern "C" int knn_flat_add_dev(knn_handle h, const float *x_dev, int64_t n, voi
     if (n == 0) return 0;
     if (!x_dev) return set_err(KNN_ERR_INVALID, "add: null pointer");
     std::lock_guard<std::mutex> lk(h->mu);
+    if (h->is_view) return set_err(KNN_ERR_INVALID, "add: a view is read-only");
     HIP_TRY(hipSetDevice(h->device));
     if (h->ntotal + n > 0xFFFFFFF0ll) return set_err(KNN_ERR_UNSUPPORTED, "add: more than 2^32 rows per index");
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
@@ -1516,6 +1543,7 @@ extern "C" int knn_flat_add(knn_handle h, const float *x_host, int64_t n)
     if (n == 0) return 0;
     if (!x_host) return set_err(KNN_ERR_INVALID, "add: null pointer");
     std::lock_guard<std::mutex> lk(h->mu);
+    if (h->is_view) return set_err(KNN_ERR_INVALID, "add: a view is read-only");
     HIP_TRY(hipSetDevice(h->device));
     if (h->ntotal + n > 0xFFFFFFF0ll) return set_err(KNN_ERR_UNSUPPORTED, "add: more than 2^32 rows per index");
     int rc = grow_index(h, h->ntotal + n);
@@ -2073,6 +2101,7 @@ extern "C" int knn_flat_normalize_rows(knn_handle h)
 {
     if (!h) return set_err(KNN_ERR_INVALID, "normalize_rows: null handle");
     std::lock_guard<std::mutex> lk(h->mu);
+    if (h->is_view) return set_err(KNN_ERR_INVALID, "normalize_rows: a view is read-only");
     if (h->ntotal == 0) return 0;
     HIP_TRY(hipSetDevice(h->device));
     int rc = normalize_dev_impl(h->xb, h->ntotal, h->d, h->dp, h->stream);
@@ -2129,6 +2158,7 @@ extern "C" int knn_flat_reserve(knn_handle h, int64_t nrows)
     if (!h) return set_err(KNN_ERR_INVALID, "reserve: null handle");
     if (nrows < 0 || nrows > 0xFFFFFFF0ll) return set_err(KNN_ERR_INVALID, "reserve: bad row count");
     std::lock_guard<std::mutex> lk(h->mu);
+    if (h->is_view) return set_err(KNN_ERR_INVALID, "reserve: a view is read-only");
     HIP_TRY(hipSetDevice(h->device));
     if (nrows <= h->cap_rows) return 0;
     // exact-size allocation (grow_index over-allocates only when it has to guess)

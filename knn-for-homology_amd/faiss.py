@@ -123,6 +123,16 @@ class IndexFlat(Index):
         _lib.check(_lib.lib().knn_flat_search_self(self._h, int(row0), nrows, k, D.ctypes.data, I.ctypes.data))
         return D, I
 
+    def view(self):
+        """A read-only second handle on the same device rows with its own stream and scratch
+        memory: searches on an index and its view overlap on the GPU (sharded.py alternates
+        between the two).  Keeps its parent alive."""
+        v = object.__new__(IndexFlat)
+        v._h = ctypes.c_void_p()
+        v._d, v._metric, v._parent = self._d, self._metric, self
+        _lib.check(_lib.lib().knn_flat_view(self._h, ctypes.byref(v._h)))
+        return v
+
     def normalize_rows(self):
         """L2-normalises the stored rows in place on the device (``faiss.normalize_L2`` applied
         to what was added, bit for bit, without the host round trip)."""

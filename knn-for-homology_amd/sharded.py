@@ -13,9 +13,13 @@ slices in insertion order, so global ids are ``row_offset + local row``.  A sear
      combines the per-chunk lists inside one GPU), so the result does not depend on the
      number of shards.
 
-torch is used for device memory, the current stream and torch.distributed only.
+``submit`` enqueues a search and returns at once; searches submitted back to back alternate
+between two lanes of the backend (the index and a read-only view of it, each with its own
+stream and scratch memory) and overlap on the GPU: the seed sample, the merges and the
+all-gather of one search run beside the scan of the other.  ``search_dev`` = submit + wait.
+
+torch is used for device memory, streams and torch.distributed only.
 """
-import contextlib
 import ctypes
 import os
 
@@ -35,64 +39,63 @@ def shard_bounds(n_total: int, world: int, rank: int):
 
 
 class HipShardBackend:
-    """Local shard scan + key merge on the rank's GPU through the C ABI."""
+    """Local shard scan + key merge on the rank's GPU through the C ABI.
+
+    Two *lanes*: the index itself and a read-only view of it (``knn_flat_view``: same rows,
+    own scratch memory), each with its own HIP stream.  Consecutive searches alternate
+    between them, so the small launches at either end of one search (seed sample, merges,
+    the all-gather) run beside the other search's scan instead of leaving the GPU idle."""
 
     def __init__(self, d, metric):
         self.index = _faiss.IndexFlat(d, metric)
         self.metric = metric
         self.device = torch.device("cuda", int(_lib.lib().knn_device_of(self.index._h)))
-        self._stream = None
+        self._lanes = None
+        self._turn = 0
 
-    @contextlib.contextmanager
-    def stream_scope(self, *inputs):
-        """Runs the enclosed launches on the backend's own (non-default) HIP stream, ordered
-        after the caller's current stream, and makes the caller's stream wait for them on exit.
-        The C ABI treats a NULL stream as "use the library's stream and synchronise"; torch's
-        default stream IS the NULL stream, so without this every search would block the host
-        and the GPU would idle between the kernels of consecutive searches."""
-        caller = torch.cuda.current_stream(self.device)
-        if self._stream is None:
-            self._stream = torch.cuda.Stream(self.device)
-        side = self._stream
-        side.wait_stream(caller)
-        for t in inputs:
-            t.record_stream(side)
-        outs = []
-        with torch.cuda.stream(side):
-            yield outs
-        caller.wait_stream(side)
-        for t in outs:
-            t.record_stream(caller)
+    def _invalidate(self):
+        self._lanes = None  # views see the rows present when they were made
+
+    def next_lane(self):
+        """(index handle object, torch stream) of the lane whose turn it is."""
+        if self._lanes is None:
+            self._lanes = [(self.index, torch.cuda.Stream(self.device)), (self.index.view(), torch.cuda.Stream(self.device))]
+        lane = self._lanes[self._turn]
+        self._turn ^= 1
+        return lane
 
     def reserve(self, n):
         _lib.check(_lib.lib().knn_flat_reserve(self.index._h, n))
 
     def add_dev(self, x: torch.Tensor):
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] == self.index.d
+        self._invalidate()
         stream = torch.cuda.current_stream(x.device).cuda_stream
         _lib.check(_lib.lib().knn_flat_add_dev(self.index._h, x.data_ptr(), x.shape[0], ctypes.c_void_p(stream)))
 
     def add(self, x: np.ndarray):
+        self._invalidate()
         self.index.add(x)
 
     @property
     def ntotal(self):
         return self.index.ntotal
 
-    def search_keys(self, q: torch.Tensor, k: int, id_base: int) -> torch.Tensor:
+    # the three device steps; `index` picks the lane, the launches go to torch's CURRENT stream
+    def search_keys(self, q: torch.Tensor, k: int, id_base: int, index=None) -> torch.Tensor:
         nq = q.shape[0]
         keys = torch.empty((nq, k), dtype=torch.int64, device=q.device)
         stream = torch.cuda.current_stream(q.device).cuda_stream
-        _lib.check(_lib.lib().knn_flat_search_keys_dev(self.index._h, q.data_ptr(), nq, k, id_base, keys.data_ptr(),
+        _lib.check(_lib.lib().knn_flat_search_keys_dev((index or self.index)._h, q.data_ptr(), nq, k, id_base, keys.data_ptr(),
                                                        ctypes.c_void_p(stream)))
         return keys
 
-    def search(self, q: torch.Tensor, k: int):
+    def search(self, q: torch.Tensor, k: int, index=None):
         nq = q.shape[0]
         D = torch.empty((nq, k), dtype=torch.float32, device=q.device)
         I = torch.empty((nq, k), dtype=torch.int64, device=q.device)
         stream = torch.cuda.current_stream(q.device).cuda_stream
-        _lib.check(_lib.lib().knn_flat_search_dev(self.index._h, q.data_ptr(), nq, k, D.data_ptr(), I.data_ptr(),
+        _lib.check(_lib.lib().knn_flat_search_dev((index or self.index)._h, q.data_ptr(), nq, k, D.data_ptr(), I.data_ptr(),
                                                   ctypes.c_void_p(stream)))
         return D, I
 
@@ -103,6 +106,23 @@ class HipShardBackend:
         _lib.check(_lib.lib().knn_merge_keys_dev(gathered.device.index or 0, self.metric, gathered.data_ptr(), nlists,
                                                  nq, k, D.data_ptr(), I.data_ptr(), ctypes.c_void_p(stream)))
         return D, I
+
+
+class PendingSearch:
+    """Result of ``ShardedFlatIndex.submit``: ``result()`` makes the caller's current stream
+    wait for the search and hands out (D, I)."""
+
+    def __init__(self, D, I, event=None):
+        self._D, self._I, self._event = D, I, event
+
+    def result(self):
+        if self._event is not None:
+            cur = torch.cuda.current_stream(self._D.device)
+            cur.wait_event(self._event)
+            self._D.record_stream(cur)
+            self._I.record_stream(cur)
+            self._event = None
+        return self._D, self._I
 
 
 class ShardedFlatIndex:
@@ -138,23 +158,40 @@ class ShardedFlatIndex:
         """Adds THIS rank's rows (global ids row_offset + insertion order)."""
         self.backend.add(x)
 
-    def search_dev(self, q, k):
-        """q: [nq, d] float32 tensor, identical on every rank.  Returns (D, I) tensors
-        holding the global result on every rank."""
+    def _search_on_current_stream(self, q, k, index=None):
+        kw = {"index": index} if index is not None else {}
+        if self.world == 1 and not self.force_collective:
+            return self.backend.search(q, k, **kw)
+        nq = q.shape[0]
+        keys = self.backend.search_keys(q, k, self.row_offset, **kw)
+        # rank-major concatenation along dim 0 == [world, nq, k]
+        gathered = torch.empty((self.world * nq, k), dtype=torch.int64, device=keys.device)
+        dist.all_gather_into_tensor(gathered, keys, group=self.group)
+        return self.backend.merge(gathered.view(self.world, nq, k), self.world, nq, k)
+
+    def submit(self, q, k) -> PendingSearch:
+        """Enqueues one search of q ([nq, d] float32, identical on every rank) and returns at once.
+        Searches submitted back to back alternate between the backend's two lanes and overlap on
+        the GPU; every rank must submit the same searches in the same order (the all-gathers
+        pair up by order).  The C ABI treats a NULL stream as "use the library's stream and
+        synchronise", and torch's default stream IS the NULL stream: the lanes' own streams are
+        also what keeps the host from blocking on every call."""
         k = int(k)
-        scope = getattr(self.backend, "stream_scope", None)
-        with (scope(q) if scope else contextlib.nullcontext([])) as outs:
-            if self.world == 1 and not self.force_collective:
-                D, I = self.backend.search(q, k)
-            else:
-                nq = q.shape[0]
-                keys = self.backend.search_keys(q, k, self.row_offset)
-                # rank-major concatenation along dim 0 == [world, nq, k]
-                gathered = torch.empty((self.world * nq, k), dtype=torch.int64, device=keys.device)
-                dist.all_gather_into_tensor(gathered, keys, group=self.group)
-                D, I = self.backend.merge(gathered.view(self.world, nq, k), self.world, nq, k)
-            outs += [D, I]
-        return D, I
+        lanes = getattr(self.backend, "next_lane", None)
+        if lanes is None:  # a backend without device streams (the CPU test backend)
+            return PendingSearch(*self._search_on_current_stream(q, k))
+        index, side = lanes()
+        side.wait_stream(torch.cuda.current_stream(q.device))
+        q.record_stream(side)
+        with torch.cuda.stream(side):
+            D, I = self._search_on_current_stream(q, k, index)
+            done = side.record_event()
+        return PendingSearch(D, I, done)
+
+    def search_dev(self, q, k):
+        """q: [nq, d] float32 tensor, identical on every rank.  Returns (D, I) tensors holding the
+        global result on every rank, ordered after the search on the caller's current stream."""
+        return self.submit(q, k).result()
 
     def search(self, x: np.ndarray, k):
         _faiss._check_matrix(x, self.d)

@@ -71,3 +71,43 @@ def test_emulated_four_shard_merge(gpu_faiss, oracle):
         Do, Io = oracle.flat_search(xb, xq, k, metric)
         assert np.array_equal(I.cpu().numpy(), Io)
         assert np.array_equal(D.cpu().numpy().view(np.uint32), Do.view(np.uint32))
+
+
+def test_submit_overlaps_two_lanes_and_matches_sync(gpu_faiss, oracle, monkeypatch):
+    """Searches submitted back to back alternate between the index and its read-only view (own
+    streams and scratch memory) and must return what a blocking search returns, in any
+    interleaving, with and without the collective path; a view refuses writes."""
+    import torch
+    from knn_for_homology_amd.sharded import ShardedFlatIndex
+    from knn_for_homology_amd._lib import Knn355Error
+    rng = np.random.default_rng(77)
+    xb = rng.standard_normal((70000, 256), dtype=np.float32)
+    qs = [rng.standard_normal((nq, 256), dtype=np.float32) for nq in (32, 7, 32, 1, 19, 32)]
+    for force in ("0", "1"):
+        monkeypatch.setenv("KNN355_FORCE_COLLECTIVE", force)
+        if force == "1" and not torch.distributed.is_initialized():
+            monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+            monkeypatch.setenv("MASTER_PORT", str(_free_port()))
+            torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        idx = ShardedFlatIndex(256, gpu_faiss.METRIC_INNER_PRODUCT)
+        idx.add(xb)
+        dev = idx.backend.device
+        pend = [idx.submit(torch.from_numpy(q).to(dev), 50) for q in qs]
+        torch.cuda.synchronize()
+        for q, p in zip(qs, pend):
+            D, I = p.result()
+            Do, Io = oracle.flat_search(xb, q, 50, 0)
+            assert np.array_equal(I.cpu().numpy(), Io) and np.array_equal(D.cpu().numpy().view(np.uint32), Do.view(np.uint32))
+        # rows added later are seen by both lanes (the view is rebuilt)
+        idx.add(xb[:1000] * 2.0)
+        D, I = idx.search(qs[0], 50)
+        x2 = np.concatenate([xb, xb[:1000] * 2.0])
+        Do, Io = oracle.flat_search(x2, qs[0], 50, 0)
+        assert np.array_equal(I, Io)
+        D2, I2 = idx.search(qs[0], 50)  # the other lane
+        assert np.array_equal(I2, Io)
+        v = idx.local.view()
+        with pytest.raises(Knn355Error):
+            v.add(xb[:8])
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()

@@ -10,7 +10,7 @@
   S-10M   10 M x 1024 generated on the device, cosine, k = 100, nq in {1, 8, 32, 1024, 10000}
   S-hnsw  S-pfam data, M in {32, 42}, efSearch 256, k = 100: build, search, recall@100 vs flat
 
-Exactness is the GPU test-suite's job (tests/ compare with the oracle); here the only result
+Exactness is the GPU test-suite's job (tests/ hold the bit-exact comparisons); here the only result
 checks are cheap invariants (duplicates adjacent, self hit first, recall of HNSW vs flat).
 usage: measure_all.py [out.json] [sets ...]
 """
