@@ -8,8 +8,12 @@ row-sharded over the N ranks (10M/N rows each, "scaling": "strong"); every rank 
 its shard for all queries, the per-shard top-k keys are exchanged with ONE RCCL
 all-gather and merged on every rank.  A "step" is one such search of the query batch
 over the whole database.  Inputs are resident in HBM before the timed region.  The K
-timed steps are submitted back to back (ShardedFlatIndex.submit): at most two searches are
-in flight, on the index's two lanes, and all K have completed when the clock stops.
+timed steps are submitted back to back (ShardedFlatIndex.submit) and all K have completed
+when the clock stops.  On several GPUs two searches are in flight, on the index's two lanes
+(--in-flight): the all-gather and the small launches at the ends of one search hide behind
+the other's scan (an 8-GPU shard on one GPU with the collective path: 1.11 -> 1.04 ms/step);
+on one GPU the steps run one after the other (two in flight bring nothing there and stretch
+the scan kernel's measured duration by the other lane's launches).
 
 Also reported on the same JSON line (N=1 only, outside the timed region):
   roofline      -- the scan kernel against the HBM roofline (it reads each shard once per
@@ -47,6 +51,9 @@ def parse():
     ap.add_argument("--nq", type=int, default=32)
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--d", type=int, default=1024)
+    ap.add_argument("--in-flight", type=int, default=0, choices=(0, 1, 2),
+                    help="searches in flight: 2 = steps alternate between the index's two lanes (the all-gather and the small "
+                         "launches of one search hide behind the other's scan), 1 = one after the other, 0 = 2 on several GPUs, 1 on one")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-batch", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
@@ -116,10 +123,14 @@ def run():
     _lib.check(L.knn_normalize_l2_dev(q.data_ptr(), nq, d, None))
     torch.cuda.synchronize()
 
+    in_flight = args.in_flight or (2 if world > 1 else 1)
+
     def step():
         # one search of the query batch, enqueued: consecutive steps alternate between the index's
         # two lanes (own stream and scratch memory each), so up to two searches are in flight and
         # the small launches at the ends of one hide behind the scan of the other
+        if in_flight == 1:
+            index.backend._turn = 0
         return index.submit(q, k)
 
     def fence():
@@ -173,7 +184,7 @@ def run():
                         f"{nq} queries per step, DB row-sharded over {world} GPU(s)"
                         + (", RCCL all-gather of per-shard top-k keys + merge" if world > 1 else ""),
             "nb_total": args.nb_total, "nb_per_gpu": nb_local, "d": d, "k": k, "queries_per_step": nq,
-            "parallelism": f"db-row-shard x{world}",
+            "parallelism": f"db-row-shard x{world}", "searches_in_flight": in_flight,
         },
     }
     if avg_scan_ms:
