@@ -85,6 +85,11 @@ def run():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
         args.gpus = world
+    # KNN355_REHEARSE_ONE_GPU=1: every rank uses GPU 0 and the collective runs over gloo (NCCL refuses two
+    # ranks per device) -- a functional rehearsal of the multi-rank path on a one-GPU box, not a measurement
+    rehearse = os.environ.get("KNN355_REHEARSE_ONE_GPU", "0") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -92,7 +97,10 @@ def run():
     if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from knn_for_homology_amd import _lib, faiss
     from knn_for_homology_amd.sharded import ShardedFlatIndex, shard_bounds
