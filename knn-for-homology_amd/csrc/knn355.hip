@@ -625,12 +625,13 @@ __device__ __forceinline__ void lists_compact(ListCtx &L, char *smem, int tile_r
     __syncthreads();
 }
 
-template <bool GLDS>
+template <bool GLDS, bool NT = false>
 __device__ __forceinline__ void stage_issue(const float *src, char *lds_wave_base, int lane, f32x4 &reg)
 {
     if constexpr (GLDS) {
+        // NT (aux bit 1 = non-temporal): for data that is read once
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                         (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+                                         (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, NT ? 2 : 0);
     } else {
         reg = *(const f32x4 *)src;
     }
@@ -650,7 +651,11 @@ __device__ __forceinline__ void sched_spread()
 // WM x WN waves; each wave owns TM x TN MFMA tiles of 32(db rows) x 32(queries)
 // SAMPLE only names the instantiation that scans a seed sample, so that profiles keep the
 // (tiny) sample launches apart from the main pass of the same configuration.
-template <int WM, int WN, int TM, int TN, bool L2, int STG, bool SAMPLE = false>
+// NTDB: the launch has ONE query tile, so every database row is read by exactly one workgroup:
+// its staging loads are non-temporal and do not displace the queries (re-read by every workgroup
+// each K step) from L2 / Infinity Cache -- 10 M x 32 queries +4 %.  With several query tiles the
+// workgroups of a chunk share the rows through L2 and non-temporal loads cost 3 %.
+template <int WM, int WN, int TM, int TN, bool L2, int STG, bool SAMPLE = false, bool NTDB = false>
 __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 {
     constexpr bool GLDS = STG == 0;
@@ -851,7 +856,8 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
             // prologue: stage K step 0 into buffer 0
 #pragma unroll
             for (int n = 0; n < NI; n++) {
-                stage_issue<GLDS>(tsrc[n], stage0 + lds_off[n], lane, sreg[n]);
+                if (GLDS && NTDB && n < DT / 32) stage_issue<GLDS, true>(tsrc[n], stage0 + lds_off[n], lane, sreg[n]); // rows, not queries
+                else stage_issue<GLDS>(tsrc[n], stage0 + lds_off[n], lane, sreg[n]);
                 if constexpr (!GLDS) *(f32x4 *)(stage0 + lds_off[n] + lane * 16) = sreg[n];
             }
             if constexpr (GLDS) {
@@ -865,7 +871,10 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 #ifdef KNN355_ABLATE_DMA
                     compute(cur, no_dma, nd_none{});
 #else
-                    compute(cur, [&](int n) { stage_issue<true>(tsrc[n] + koff, nxt + lds_off[n], lane, sreg[n]); }, nd_all{});
+                    compute(cur, [&](int n) {
+                        if (NTDB && n < DT / 32) stage_issue<true, true>(tsrc[n] + koff, nxt + lds_off[n], lane, sreg[n]);
+                        else stage_issue<true>(tsrc[n] + koff, nxt + lds_off[n], lane, sreg[n]);
+                    }, nd_all{});
 #endif
                 }
                 __syncthreads();
@@ -1689,6 +1698,10 @@ static int launch_scan_cfg(const knn_index_s *h, const ScanParams &p, const Scan
     else
         kern = stg == 0 ? flat_scan_kernel<WM, WN, TM, TN, false, 0> : (stg == 1 ? flat_scan_kernel<WM, WN, TM, TN, false, 1> : flat_scan_kernel<WM, WN, TM, TN, false, 2>);
     if (sample && stg == 0) kern = l2 ? flat_scan_kernel<WM, WN, TM, TN, true, 0, true> : flat_scan_kernel<WM, WN, TM, TN, false, 0, true>;
+    if (stg == 0 && p.nqtiles == 1 && !(h->flags & 32)) { // one query tile: rows are read once (flags & 32: plain loads, A/B)
+        if (sample) kern = l2 ? flat_scan_kernel<WM, WN, TM, TN, true, 0, true, true> : flat_scan_kernel<WM, WN, TM, TN, false, 0, true, true>;
+        else kern = l2 ? flat_scan_kernel<WM, WN, TM, TN, true, 0, false, true> : flat_scan_kernel<WM, WN, TM, TN, false, 0, false, true>;
+    }
     HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds));
     hipLaunchKernelGGL(kern, dim3(plan.grid), dim3(256), plan.lds, s, p);
     HIP_TRY(hipGetLastError());

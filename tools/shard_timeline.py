@@ -19,7 +19,14 @@ rows.sort()
 names = [r[2] for r in rows]
 short = lambda n: n.split("(")[0][:70]
 idx = [i for i, n in enumerate(names) if "flat_scan_kernel" in n and ", true>" not in n.replace("1, true", "")]
-main = [i for i, n in enumerate(names) if "flat_scan_kernel" in n and not n.rstrip(">").endswith("true")]
+def _is_main(n):
+    if "flat_scan_kernel<" not in n:
+        return False
+    targs = n[n.index("flat_scan_kernel<") + len("flat_scan_kernel<"):].split(">")[0].split(", ")
+    return not (len(targs) > 6 and targs[6] == "true")
+
+
+main = [i for i, n in enumerate(names) if _is_main(n)]
 if len(main) < show + 3:
     print("too few steps", len(main)); sys.exit(1)
 # take steps from the tail (steady state)

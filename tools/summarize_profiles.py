@@ -25,8 +25,10 @@ if bench_json.exists():
 
 
 def short(name):
-    if "flat_scan_kernel" in name and name.rstrip(">(ScanParams) ").endswith("true"):
-        return "flat_scan_sample_pass"
+    if "flat_scan_kernel<" in name:
+        targs = name[name.index("flat_scan_kernel<") + len("flat_scan_kernel<"):].split(">")[0].split(", ")
+        if len(targs) > 6 and targs[6] == "true":  # <WM, WN, TM, TN, L2, STG, SAMPLE, NTDB>
+            return "flat_scan_sample_pass"
     if "flat_scan_kernel<4, 1, 2, 1" in name:
         return "flat_scan_q32_d256"
     if "flat_scan_kernel<2, 2, 2, 1" in name:
