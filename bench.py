@@ -123,7 +123,7 @@ def run():
         x = torch.randn((m, d), generator=gen, device=dev, dtype=torch.float32)
         _lib.check(L.knn_normalize_l2_dev(x.data_ptr(), m, d, None))
         index.add_dev(x)
-        if first_rows is None and rank == 0 and not args.no_cpu:
+        if first_rows is None and rank == 0 and world == 1 and not args.no_cpu:
             first_rows = x[: min(m, args.cpu_sample_rows)].cpu().numpy()
         del x
     q_host = np.random.default_rng(24).standard_normal((nq, d), dtype=np.float32)
