@@ -8,10 +8,8 @@ pfam/search.py:42-53  search_flat: IndexFlat inner product, k = 1000 ->
 pfam/search.py:56-61  main: both searches for subset10_t5 and subset10
 """
 from pathlib import Path
-from typing import Tuple
 
 import numpy
-from numpy import ndarray
 
 from .. import faiss
 from ..paths import subset10, subset10_t5
@@ -20,48 +18,55 @@ K = 1000
 LSH_BITS = 1024
 
 
-def load_embeddings(embedding_set: Path) -> Tuple[ndarray, ndarray]:
-    out = []
-    for name in ("train.npy", "test.npy"):
-        x = numpy.load(Path(embedding_set) / name).astype(numpy.float32)
-        faiss.normalize_L2(x)
-        out.append(x)
-    return out[0], out[1]
+def _normalised(npy: Path):
+    vectors = numpy.load(npy).astype(numpy.float32)
+    faiss.normalize_L2(vectors)
+    return vectors
+
+
+def load_embeddings(embedding_set: Path):
+    """(train, test), float32 and L2-normalised."""
+    folder = Path(embedding_set)
+    return _normalised(folder / "train.npy"), _normalised(folder / "test.npy")
+
+
+def _filled(index, rows):
+    index.train(rows)
+    index.add(rows)
+    return index
+
+
+def _search_and_store(folder: Path, stem: str, index, queries, k: int):
+    """``<stem>_scores.npy`` / ``<stem>_hits.npy`` in the embedding set's directory."""
+    scores, hits = index.search(queries, k)
+    for suffix, array in (("scores", scores), ("hits", hits)):
+        numpy.save(folder / f"{stem}_{suffix}.npy", array)
 
 
 def search_index(embedding_set: Path, k: int = K):
-    embedding_set = Path(embedding_set)
-    train, test = load_embeddings(embedding_set)
-    cache = embedding_set / f"index_lsh_{LSH_BITS}.bin"
-    if cache.is_file():
-        lsh_index = faiss.read_index(str(cache))
+    folder = Path(embedding_set)
+    train, test = load_embeddings(folder)
+    cached = folder / f"index_lsh_{LSH_BITS}.bin"
+    if cached.is_file():
+        lsh = faiss.read_index(str(cached))
     else:
-        lsh_index = faiss.IndexLSH(train.shape[1], LSH_BITS)
-        lsh_index.train(train)
-        lsh_index.add(train)
-        faiss.write_index(lsh_index, str(cache))
-    scores, hits = lsh_index.search(test, k)
-    numpy.save(embedding_set / "index_scores.npy", scores)
-    numpy.save(embedding_set / "index_hits.npy", hits)
+        lsh = _filled(faiss.IndexLSH(train.shape[1], LSH_BITS), train)
+        faiss.write_index(lsh, str(cached))
+    _search_and_store(folder, "index", lsh, test, k)
 
 
 def search_flat(embedding_set: Path, k: int = K):
-    embedding_set = Path(embedding_set)
-    train, test = load_embeddings(embedding_set)
-    index = faiss.IndexFlat(train.shape[1], faiss.METRIC_INNER_PRODUCT)
-    index.train(train)
-    index.add(train)
-    scores, hits = index.search(test, k)
-    numpy.save(embedding_set / "flat_scores.npy", scores)
-    numpy.save(embedding_set / "flat_hits.npy", hits)
+    folder = Path(embedding_set)
+    train, test = load_embeddings(folder)
+    flat = _filled(faiss.IndexFlat(train.shape[1], faiss.METRIC_INNER_PRODUCT), train)
+    _search_and_store(folder, "flat", flat, test, k)
 
 
 def main():
     for embedding_set in (subset10_t5(), subset10()):
-        print(embedding_set, "index")
-        search_index(embedding_set)
-        print(embedding_set, "flat")
-        search_flat(embedding_set)
+        for label, run in (("index", search_index), ("flat", search_flat)):
+            print(embedding_set, label)
+            run(embedding_set)
 
 
 if __name__ == "__main__":

@@ -9,7 +9,6 @@ only asserts that the file exists (tests/test_utils.py:17-21).
 import argparse
 import logging
 from pathlib import Path
-from typing import Optional, Sequence
 
 import numpy
 
@@ -17,30 +16,39 @@ from .. import faiss
 
 logger = logging.getLogger(__name__)
 
-
-def _parser() -> argparse.ArgumentParser:
-    p = argparse.ArgumentParser()
-    p.add_argument("--dir", type=Path, default=Path(), help="The name of the directory containing the database")
-    p.add_argument("--index", type=Path, required=True, help="The location to write the index to")
-    p.add_argument("--param", type=int, default=1024,
-                   help="The tuning parameter of the index. Higher means higher precision")
-    return p
+# option -> argparse keywords (same names, defaults and help texts as the reference's parser)
+_OPTIONS = {
+    "--dir": dict(type=Path, default=Path(), help="The name of the directory containing the database"),
+    "--index": dict(type=Path, required=True, help="The location to write the index to"),
+    "--param": dict(type=int, default=1024, help="The tuning parameter of the index. Higher means higher precision"),
+}
 
 
-def main(args: Optional[Sequence[str]] = None):
+def parse_options(argv=None):
+    parser = argparse.ArgumentParser()
+    for flag, spec in _OPTIONS.items():
+        parser.add_argument(flag, **spec)
+    return parser.parse_args(argv)
+
+
+def build_lsh_index(database, nbits):
+    """IndexLSH over ``database`` (any float dtype: faiss wants float32), trained and filled."""
+    vectors = numpy.ascontiguousarray(database, dtype=numpy.float32)
+    logger.info(f"Training LSH index with {nbits} bits on {vectors.shape}")
+    index = faiss.IndexLSH(vectors.shape[1], nbits)
+    index.train(vectors)
+    index.add(vectors)
+    return index
+
+
+def main(args=None):
     logging.basicConfig(level=logging.INFO, format="%(asctime)s %(message)s")
-    opts = _parser().parse_args(args)
-    train_file = opts.dir / "train.npy"
-    logger.info(f"Loading database from {train_file}")
-    embeddings = numpy.load(str(train_file))
-    if embeddings.dtype != numpy.float32:
-        embeddings = embeddings.astype(numpy.float32)
-    logger.info(f"Training LSH index with {opts.param} bits on {embeddings.shape}")
-    lsh_index = faiss.IndexLSH(embeddings.shape[1], opts.param)
-    lsh_index.train(embeddings)
-    lsh_index.add(embeddings)
+    options = parse_options(args)
+    source = options.dir / "train.npy"
+    logger.info(f"Loading database from {source}")
+    index = build_lsh_index(numpy.load(str(source)), options.param)
     logger.info("Writing out the LSH index")
-    faiss.write_index(lsh_index, str(opts.index))
+    faiss.write_index(index, str(options.index))
 
 
 if __name__ == "__main__":

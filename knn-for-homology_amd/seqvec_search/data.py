@@ -1,46 +1,66 @@
-"""Dataset descriptor with the same fields as the reference's ``LoadedData``
-(seqvec_search/data.py:9-50): a directory holding train/test ``.npy`` embeddings,
-``.json`` id lists, ``ids_to_family.json`` and the FASTA files."""
+"""Dataset descriptor with the fields, properties and constructor of the reference's
+``LoadedData`` (seqvec_search/data.py:9-50): a directory holding train/test ``.npy``
+embeddings, ``.json`` id lists, ``ids_to_family.json`` and the FASTA files."""
 import json
-from dataclasses import dataclass
 from pathlib import Path
-from typing import Dict, List, Optional
 
 from .constants import default_hits
 
+# (attribute, file inside the dataset directory or None, loader)
+_LAYOUT = (
+    ("train", "train.npy", None),
+    ("train_ids", "train.json", json.loads),
+    ("test", "test.npy", None),
+    ("test_ids", "test.json", json.loads),
+    ("ids_to_family", "ids_to_family.json", json.loads),
+    ("train_sequences", "train.fasta", None),
+    ("test_sequences", "test.fasta", None),
+)
+_ORDER = ("path", "train", "train_ids", "knn_index", "test", "test_ids", "ids_to_family", "train_sequences",
+          "test_sequences", "hits")
 
-@dataclass
+
 class LoadedData:
-    path: Path
-    train: Path
-    train_ids: List[str]
-    knn_index: Optional[Path]
-    test: Path
-    test_ids: List[str]
-    ids_to_family: Dict[str, str]
-    train_sequences: Path
-    test_sequences: Path
-    hits: int = default_hits
+    """Positional / keyword construction in the reference's field order; ``hits`` defaults to
+    ``default_hits``.  Compares and prints like the reference's dataclass."""
 
-    @property
-    def mmseqs_dir(self) -> Path:
-        return self.path / "mmseqs_dbs"
+    def __init__(self, *args, **kwargs):
+        values = dict(zip(_ORDER, args))
+        if len(args) > len(_ORDER):
+            raise TypeError(f"LoadedData takes at most {len(_ORDER)} arguments")
+        for key, value in kwargs.items():
+            if key not in _ORDER or key in values:
+                raise TypeError(f"LoadedData: unexpected or repeated argument {key!r}")
+            values[key] = value
+        values.setdefault("hits", default_hits)
+        missing = [name for name in _ORDER if name not in values]
+        if missing:
+            raise TypeError(f"LoadedData: missing {', '.join(missing)}")
+        for name in _ORDER:
+            setattr(self, name, values[name])
 
-    @property
-    def mmseqs_test(self) -> Path:
-        return self.mmseqs_dir / "test"
+    def _astuple(self):
+        return tuple(getattr(self, name) for name in _ORDER)
 
-    @property
-    def mmseqs_train(self) -> Path:
-        return self.mmseqs_dir / "train"
+    def __eq__(self, other):
+        return isinstance(other, LoadedData) and self._astuple() == other._astuple()
+
+    def __repr__(self):
+        return "LoadedData(" + ", ".join(f"{name}={getattr(self, name)!r}" for name in _ORDER) + ")"
+
+    def _mmseqs(self, leaf=None):
+        base = Path(self.path) / "mmseqs_dbs"
+        return base if leaf is None else base / leaf
+
+    mmseqs_dir = property(lambda self: self._mmseqs())
+    mmseqs_test = property(lambda self: self._mmseqs("test"))
+    mmseqs_train = property(lambda self: self._mmseqs("train"))
 
     @classmethod
-    def from_options(cls, path: Path, hits: int = default_hits, knn_index: Optional[Path] = None) -> "LoadedData":
-        path = Path(path)
-
-        def ids(name):
-            return json.loads((path / name).read_text())
-
-        return cls(path=path, train=path / "train.npy", train_ids=ids("train.json"), knn_index=knn_index,
-                   test=path / "test.npy", test_ids=ids("test.json"), ids_to_family=ids("ids_to_family.json"),
-                   train_sequences=path / "train.fasta", test_sequences=path / "test.fasta", hits=hits)
+    def from_options(cls, path, hits=default_hits, knn_index=None):
+        root = Path(path)
+        found = {}
+        for attribute, filename, loader in _LAYOUT:
+            location = root / filename
+            found[attribute] = loader(location.read_text()) if loader else location
+        return cls(path=root, knn_index=knn_index, hits=hits, **found)
