@@ -407,3 +407,53 @@ def test_large_shard_streaming(gpu_faiss, oracle):
     sub.add(win)
     Ds, Is = sub.search(q[:8], k)
     _assert_same(Ds, Is, *oracle.flat_search(win, q[:8], k, 0))
+
+
+def test_full_size_10m_streaming(gpu_faiss, oracle):
+    """BASELINE config 4 at its full single-GPU size: 10 M x 1024 rows resident (41 GB), inner
+    product, k = 100, 32 queries.  Size-independent properties: planted queries find themselves
+    first with score 1; scores descend, ids are valid and distinct; the seeded plan, an unseeded
+    plan with another chunk count and a 128-query-tile plan return the same bits; a 200 k-row
+    window around planted rows equals the oracle bit for bit."""
+    import torch
+    from knn_for_homology_amd import _lib
+    L = _lib.lib()
+    nb, d, k = 10_000_000, 1024, 100
+    dev = torch.device("cuda:0")
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 60 * (1 << 30):
+        pytest.skip("needs 60 GB of free HBM")
+    g = torch.Generator(device=dev)
+    g.manual_seed(23)
+    idx = gpu_faiss.IndexFlat(d, 0)
+    _lib.check(L.knn_flat_reserve(idx._h, nb))
+    for i0 in range(0, nb, 1_000_000):
+        x = torch.randn((1_000_000, d), generator=g, device=dev)
+        _lib.check(L.knn_normalize_l2_dev(x.data_ptr(), 1_000_000, d, None))
+        _lib.check(L.knn_flat_add_dev(idx._h, x.data_ptr(), 1_000_000, None))
+        del x
+    assert idx.ntotal == nb
+    planted = np.array([0, 7, 4_999_999, 7_654_321, nb - 1])
+    q = np.concatenate([idx.reconstruct(int(i))[None] for i in planted]
+                       + [np.random.default_rng(24).standard_normal((27, d), dtype=np.float32)])
+    gpu_faiss.normalize_L2(q)
+    D, I = idx.search(q, k)
+    assert idx.last_scan()["kernel"] == "flat_scan_q32_d256"
+    assert (I[:5, 0] == planted).all() and np.allclose(D[:5, 0], 1.0, atol=1e-5)
+    assert (np.diff(D, axis=1) <= 0).all() and I.min() >= 0 and I.max() < nb
+    srt = np.sort(I, axis=1)
+    assert (srt[:, 1:] != srt[:, :-1]).all()
+    for qt, nch, flags in ((0, 301, 8), (128, 0, 0)):
+        idx.set_tuning(qt, nch, flags)
+        D2, I2 = idx.search(q, k)
+        _assert_same(D2, I2, D, I)
+    w0 = 7_600_000
+    win = idx.reconstruct_n(w0, 200_000)
+    sub = gpu_faiss.IndexFlat(d, 0)
+    sub.add(win)
+    Ds, Is = sub.search(q[:8], k)
+    _assert_same(Ds, Is, *oracle.flat_search(win, q[:8], k, 0))
+    # every window row that made the global top-k must also be in the window's own top-k
+    for r in range(8):
+        inside = I[r][(I[r] >= w0) & (I[r] < w0 + 200_000)] - w0
+        assert np.isin(inside, Is[r]).all()
