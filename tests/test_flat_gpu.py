@@ -457,3 +457,38 @@ def test_full_size_10m_streaming(gpu_faiss, oracle):
     for r in range(8):
         inside = I[r][(I[r] >= w0) & (I[r] < w0 + 200_000)] - w0
         assert np.isin(inside, Is[r]).all()
+
+
+def test_pfam_sized_all_vs_all(gpu_faiss, oracle):
+    """BASELINE config 3 at full size: 200 000 x 1024 clustered rows with 0.5 % exact duplicates,
+    cosine all-vs-all, k = 1000 (the reference's pfam/proteins_search.py run), through the pipelined
+    host path.  Properties over all rows + the oracle's bits on sampled rows."""
+    n, d, k = 200_000, 1024, 1000
+    cent = np.random.default_rng(21).standard_normal((2000, d)).astype(np.float32)
+    rng = np.random.default_rng(22)
+    x = cent[rng.integers(0, 2000, n)] + 0.35 * rng.standard_normal((n, d), dtype=np.float32)
+    dst = rng.choice(n, n // 200, replace=False)
+    src = (dst + 1 + rng.integers(0, n - 1, dst.size)) % n
+    keep = ~np.isin(src, dst)
+    dst, src = dst[keep], src[keep]
+    x[dst] = x[src]
+    gpu_faiss.normalize_L2(x)
+    idx = gpu_faiss.IndexFlat(d, gpu_faiss.METRIC_INNER_PRODUCT)
+    idx.add(x)
+    D, I = idx.search_self(k)
+    assert D.shape == (n, k) and I.dtype == np.int64
+    assert (np.diff(D, axis=1) <= 0).all() and I.min() >= 0 and I.max() < n
+    # a row is its own best hit unless an exact duplicate with a lower id ties with it
+    lower_twin = np.full(n, -1)
+    a, b = np.minimum(dst, src), np.maximum(dst, src)
+    lower_twin[b] = a
+    expect_first = np.where(lower_twin >= 0, lower_twin, np.arange(n))
+    has_twin = np.zeros(n, bool)
+    has_twin[a] = has_twin[b] = True
+    assert (I[~has_twin, 0] == np.arange(n)[~has_twin]).all()
+    assert (np.isin(I[has_twin, 0], np.concatenate([a, b]))).all() and (I[b, 0] <= b).all() and (I[expect_first == np.arange(n), 0] <= np.arange(n)[expect_first == np.arange(n)]).all()
+    sample = np.concatenate([rng.choice(n, 12, replace=False), a[:2], b[:2]])
+    Do, Io = oracle.flat_search(x, x[sample], k, 0)
+    _assert_same(D[sample], I[sample], Do, Io)
+    for r in rng.choice(n, 64, replace=False):  # no id twice in a row of results
+        assert len(np.unique(I[r])) == k
