@@ -107,9 +107,11 @@ int knn_flat_view(knn_handle parent, knn_handle *out);
 int knn_flat_search_keys_dev(knn_handle h, const float *q_dev, int64_t nq, int64_t k,
                              uint32_t id_base, uint64_t *keys_dev, void *stream);
 /* merges nlists key lists per query ([nlists][nq][k], e.g. an all-gather
- * buffer) into final D/I on the given device */
-int knn_merge_keys_dev(int32_t device, int32_t metric, const uint64_t *keys_dev, int32_t nlists,
-                       int64_t nq, int64_t k, float *D_dev, int64_t *I_dev, void *stream);
+ * buffer) into final D/I on h's device, in h's metric; intermediate rounds (nlists * k >
+ * 4096) use scratch memory owned by h, so merges issued through different handles (an
+ * index and its view, on two streams) never share a buffer */
+int knn_merge_keys_dev(knn_handle h, const uint64_t *keys_dev, int32_t nlists, int64_t nq, int64_t k,
+                       float *D_dev, int64_t *I_dev, void *stream);
 /* pre-sizes the device storage for nrows rows (faiss has no equivalent; avoids
  * regrowth copies when a shard is filled by several add calls) */
 int knn_flat_reserve(knn_handle h, int64_t nrows);

@@ -44,7 +44,7 @@ def _declare(L):
         "knn_flat_normalize_rows": (c_int32, [H]),
         "knn_flat_view": (c_int32, [H, POINTER(H)]),
         "knn_flat_search_keys_dev": (c_int32, [H, c_void_p, c_int64, c_int64, c_uint32, c_void_p, c_void_p]),
-        "knn_merge_keys_dev": (c_int32, [c_int32, c_int32, c_void_p, c_int32, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+        "knn_merge_keys_dev": (c_int32, [H, c_void_p, c_int32, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
         "knn_ntotal": (c_int64, [H]),
         "knn_dim": (c_int32, [H]),
         "knn_metric": (c_int32, [H]),

@@ -35,6 +35,8 @@
 #include <math.h>
 #include <algorithm>
 #include <mutex>
+#include <memory>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -255,8 +257,7 @@ __device__ __forceinline__ int wave_inclusive_scan(int x)
 }
 
 template <int R, typename LD>
-__device__ __attribute__((noinline)) int wave_select(LD load, int n, int k, int kmax, int lane, uint32_t *thr_ord, uint64_t *dst,
-                                                     uint32_t *hist)
+__device__ __attribute__((noinline)) int wave_select(LD load, int n, int k, int kmax, int lane, uint32_t *thr_ord, uint64_t *dst)
 {
     static_assert(R <= 64, "at most 4096 keys per wave");
     // wave-uniform by contract; arguments of a non-inlined function arrive in VGPRs and the
@@ -309,51 +310,7 @@ __device__ __attribute__((noinline)) int wave_select(LD load, int n, int k, int 
             cnt = real;
         }
     }
-    if (mn != mx && hist) {
-        // Experiment (flags & 256): byte-wise radix select through a 256-bin LDS histogram private
-        // to this wave: at most four passes (leading bytes shared by all keys are skipped), each
-        // pass one LDS atomic per key still matching the prefix, one ds_read_b128 + DPP scan over
-        // the bins.  Measured: no faster than the bitwise search in the scan kernels and slower
-        // in the merge (scores crowd into a few bins, the atomics serialise).
-        int shift = 24;
-        while (shift > 0 && (mn >> shift) == (mx >> shift)) shift -= 8;
-        uint32_t prefix = shift == 24 ? 0u : (mx >> (shift + 8)) << (shift + 8);
-        int c_below = 0; // keys strictly below the current prefix range
-        for (;;) {
-            *(uint4 *)(hist + 4 * lane) = make_uint4(0u, 0u, 0u, 0u);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            const uint32_t pmask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8)); // bits already decided
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                if (((hi[r] ^ prefix) & pmask) == 0u) atomicAdd(&hist[(hi[r] >> shift) & 255u], 1u);
-                if ((r & 15) == 15) __builtin_amdgcn_sched_barrier(0);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            const uint4 h4 = *(const uint4 *)(hist + 4 * lane);
-            const int s4 = (int)(h4.x + h4.y + h4.z + h4.w);
-            const int incl = wave_inclusive_scan(s4);
-            const int need = k - c_below;
-            const uint64_t m = __ballot(incl >= need);
-            const int Ls = m ? __builtin_ctzll(m) : 63;
-            int cum = __builtin_amdgcn_readlane(incl - s4, Ls);
-            const int b0 = __builtin_amdgcn_readlane((int)h4.x, Ls), b1 = __builtin_amdgcn_readlane((int)h4.y, Ls);
-            const int b2 = __builtin_amdgcn_readlane((int)h4.z, Ls), b3 = __builtin_amdgcn_readlane((int)h4.w, Ls);
-            int bin = 4 * Ls, cb = b0;
-            if (cum + b0 < need) { cum += b0; bin++; cb = b1;
-                if (cum + b1 < need) { cum += b1; bin++; cb = b2;
-                    if (cum + b2 < need) { cum += b2; bin++; cb = b3; } } }
-            const int c_le = c_below + cum + cb; // keys whose word is <= the top of this bin
-            const uint32_t top = prefix | ((uint32_t)bin << shift) | ((shift ? (1u << shift) : 1u) - 1u);
-            if (c_le <= kmax || shift == 0) {
-                T = top; // shift == 0: the exact k-th smallest word
-                cnt = c_le;
-                break;
-            }
-            c_below += cum;
-            prefix |= (uint32_t)bin << shift;
-            shift -= 8;
-        }
-    } else if (mn != mx && cnt > kmax) {
+    if (mn != mx && cnt > kmax) {
         // Bracket search on the score word for an X with k <= #(keys < X) <= kmax.  f(X) = #(keys < X)
         // is monotone, f(mn) = 0 < k and f(mx + 1) = cnt > kmax.  Probes alternate between linear
         // interpolation of the target rank inside the bracket (scores between mn and mx are close
@@ -447,14 +404,13 @@ __device__ __attribute__((noinline)) int wave_select(LD load, int n, int k, int 
     return min(total, kmax);
 }
 
-// hist: 256 x uint32 of LDS private to the calling wave (radix select), or nullptr (binary search)
 template <typename LD>
 __device__ __forceinline__ int wave_select_dispatch(int R, LD load, int n, int k, int kmax, int lane,
-                                                    uint32_t *thr_ord, uint64_t *dst, uint32_t *hist)
+                                                    uint32_t *thr_ord, uint64_t *dst)
 {
-    if (R <= 8) return wave_select<8, LD>(load, n, k, kmax, lane, thr_ord, dst, hist);
-    if (R <= 16) return wave_select<16, LD>(load, n, k, kmax, lane, thr_ord, dst, hist);
-    return wave_select<32, LD>(load, n, k, kmax, lane, thr_ord, dst, hist); // callers guarantee n <= 2048
+    if (R <= 8) return wave_select<8, LD>(load, n, k, kmax, lane, thr_ord, dst);
+    if (R <= 16) return wave_select<16, LD>(load, n, k, kmax, lane, thr_ord, dst);
+    return wave_select<32, LD>(load, n, k, kmax, lane, thr_ord, dst); // callers guarantee n <= 2048
 }
 
 // The merge kernel may also use 64 keys per lane (4096 keys): it is its own kernel, so the
@@ -462,16 +418,16 @@ __device__ __forceinline__ int wave_select_dispatch(int R, LD load, int n, int k
 // (a non-inlined callee's registers count for every kernel that can reach it).
 template <int RMAX, typename LD>
 __device__ __forceinline__ int wave_select_dispatch_max(int R, LD load, int n, int k, int kmax, int lane,
-                                                        uint32_t *thr_ord, uint64_t *dst, uint32_t *hist)
+                                                        uint32_t *thr_ord, uint64_t *dst)
 {
     if constexpr (RMAX <= 16) {
-        if (R <= 8) return wave_select<8, LD>(load, n, k, kmax, lane, thr_ord, dst, hist);
-        return wave_select<16, LD>(load, n, k, kmax, lane, thr_ord, dst, hist);
+        if (R <= 8) return wave_select<8, LD>(load, n, k, kmax, lane, thr_ord, dst);
+        return wave_select<16, LD>(load, n, k, kmax, lane, thr_ord, dst);
     } else if constexpr (RMAX <= 32) {
-        return wave_select_dispatch(R, load, n, k, kmax, lane, thr_ord, dst, hist);
+        return wave_select_dispatch(R, load, n, k, kmax, lane, thr_ord, dst);
     } else {
-        if (R <= 32) return wave_select_dispatch(R, load, n, k, kmax, lane, thr_ord, dst, hist);
-        return wave_select<64, LD>(load, n, k, kmax, lane, thr_ord, dst, hist);
+        if (R <= 32) return wave_select_dispatch(R, load, n, k, kmax, lane, thr_ord, dst);
+        return wave_select<64, LD>(load, n, k, kmax, lane, thr_ord, dst);
     }
 }
 
@@ -497,7 +453,6 @@ struct ScanParams {
     int skip_mask;     // >= 0: rows whose 8-row block b has (b & skip_mask) == 0 belong to the seed sample, skip them
     int kslot;         // keys per (query, list) slot in `partial`: k + k/4
     int partial_lists; // lists per query in `partial` (nchunks, +1 when a seed list rides along)
-    int dbg;           // timing experiments only: 2 = skip compaction, 4 = skip appends
 };
 
 // Views: view row r of a launch with stride row_mul is database row
@@ -529,7 +484,6 @@ struct ListCtx {
     uint32_t *gthr;   // [QT] shared running thresholds of these queries
     int cap, k;
     int kslot;        // size of this workgroup's output slot per query (k + k/4)
-    int use_hist;     // radix select through an LDS histogram (0: bitwise binary search)
 
     __device__ __forceinline__ void init(int tid, int QT, int nthreads = 256)
     {
@@ -564,7 +518,6 @@ __device__ __forceinline__ void lists_compact(ListCtx &L, char *smem, int tile_r
 {
     const int lane = tid & 63, wave = tid >> 6;
     const int R = L.cap >> 6;
-    uint32_t *hist = L.use_hist ? (uint32_t *)smem + 256 * wave : nullptr; // staging LDS is idle between tiles
     if (R <= 32) {
         // one wave per query, registers only: one query in flight per wave of the workgroup
         for (int ql = wave; ql < QT; ql += NT / 64) {
@@ -573,7 +526,9 @@ __device__ __forceinline__ void lists_compact(ListCtx &L, char *smem, int tile_r
             uint32_t T = 0;
             if (!last_tile) {
                 if (n <= L.cap - tile_rows) continue;
-                const int cnt = wave_select_dispatch(R, LoadContig{lst}, n, L.k, L.k + (L.k >> 2), lane, &T, lst, hist);
+                // at most cap - tile_rows keys may stay: the next tile can append tile_rows more
+                // (k in (1433, 1536] with 256-row tiles: 1.25 k alone would leave too little room)
+                const int cnt = wave_select_dispatch(R, LoadContig{lst}, n, L.k, min(L.k + (L.k >> 2), L.cap - tile_rows), lane, &T, lst);
                 if (lane == 0) {
                     L.s_cnt[ql] = cnt;
                     L.s_thr[ql] = ord2f(T);
@@ -583,7 +538,7 @@ __device__ __forceinline__ void lists_compact(ListCtx &L, char *smem, int tile_r
                 if (ql >= nq_valid) continue;
                 uint64_t *out = out_base + (size_t)ql * out_stride;
                 if (n > L.kslot) {
-                    const int cnt = wave_select_dispatch(R, LoadContig{lst}, n, L.k, L.kslot, lane, &T, out, hist);
+                    const int cnt = wave_select_dispatch(R, LoadContig{lst}, n, L.k, L.kslot, lane, &T, out);
                     for (int i = cnt + lane; i < L.kslot; i += 64) out[i] = KEY_PAD;
                     if (lane == 0) atomicMin(&L.gthr[ql], T);
                 } else {
@@ -625,16 +580,13 @@ __device__ __forceinline__ void lists_compact(ListCtx &L, char *smem, int tile_r
     __syncthreads();
 }
 
-template <bool GLDS, bool NT = false>
-__device__ __forceinline__ void stage_issue(const float *src, char *lds_wave_base, int lane, f32x4 &reg)
+// one staging instruction: 64 lanes x 16 B straight from global memory into LDS (LDS-DMA, no VGPR
+// round trip).  NT (aux bit 1 = non-temporal): for data that is read once.
+template <bool NT = false>
+__device__ __forceinline__ void stage_issue(const float *src, char *lds_wave_base)
 {
-    if constexpr (GLDS) {
-        // NT (aux bit 1 = non-temporal): for data that is read once
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                         (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, NT ? 2 : 0);
-    } else {
-        reg = *(const f32x4 *)src;
-    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, NT ? 2 : 0);
 }
 
 // scheduling pattern "PER MFMAs, one vector-memory instruction", N times
@@ -655,10 +607,9 @@ __device__ __forceinline__ void sched_spread()
 // its staging loads are non-temporal and do not displace the queries (re-read by every workgroup
 // each K step) from L2 / Infinity Cache -- 10 M x 32 queries +4 %.  With several query tiles the
 // workgroups of a chunk share the rows through L2 and non-temporal loads cost 3 %.
-template <int WM, int WN, int TM, int TN, bool L2, int STG, bool SAMPLE = false, bool NTDB = false>
+template <int WM, int WN, int TM, int TN, bool L2, bool SAMPLE = false, bool NTDB = false>
 __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 {
-    constexpr bool GLDS = STG == 0;
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int DT = WM * TM * 32;        // database rows per tile
     constexpr int QT = WN * TN * 32;        // queries per workgroup
@@ -693,7 +644,6 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
     L.cap = p.cap;
     L.k = p.k;
     L.kslot = p.kslot;
-    L.use_hist = (p.dbg & 256) != 0; // experiment: LDS-histogram radix select instead of the bitwise search
     L.init(tid, QT);
     __syncthreads();
     // per-lane staging bookkeeping: instruction ii covers combined rows 8*ii..8*ii+7
@@ -774,12 +724,6 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
             auto substep = [&](auto t_tag) {
                 constexpr int t = decltype(t_tag)::value;
                 if constexpr (t < 3) frag(t + 1);
-#ifdef KNN355_ABLATE_MFMA // timing experiment: fragments read, no MFMA
-#pragma unroll
-                for (int a = 0; a < TM; a++) asm volatile("" ::"v"(af[t & 1][a]));
-#pragma unroll
-                for (int b = 0; b < TN; b++) asm volatile("" ::"v"(bf[t & 1][b]));
-#else
 #pragma unroll
                 for (int m = 0; m < 4; m++)
 #pragma unroll
@@ -787,7 +731,6 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 #pragma unroll
                         for (int b = 0; b < TN; b++)
                             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t & 1][a][m], bf[t & 1][b][m], acc[a][b], 0, 0, 0);
-#endif
                 // staging instructions [n0, n1) of the next K step belong to this sub-step; all of
                 // them go out in the first half of the K step so that the second half covers
                 // their latency before the next barrier's vmcnt(0)
@@ -812,90 +755,24 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
         auto no_dma = [](int) {};
         using nd_none = std::integral_constant<int, 0>;
         using nd_all = std::integral_constant<int, NI>;
-        if constexpr (STG == 2) {
-            // Register ring: stage s+1 and s+2 are in flight in VGPRs while stage s is multiplied
-            // from LDS -- twice the bytes in flight of the double-buffered LDS-DMA form without
-            // more LDS.  ra holds odd stages, rb even ones (>= 2); plain loads, so the compiler's
-            // counted vmcnt leaves the younger register set in flight and __syncthreads() is a
-            // bare s_barrier.
-            f32x4 ra[NI], rb[NI];
+        // prologue: stage K step 0 into buffer 0
 #pragma unroll
-            for (int n = 0; n < NI; n++) ra[n] = *(gptr4)(tsrc[n]);
-#pragma unroll
-            for (int n = 0; n < NI; n++) *(f32x4 *)(stage0 + lds_off[n] + lane * 16) = ra[n];
-            // loads are issued unconditionally (stage index clamped): a load that only happens
-            // on some paths makes the compiler fall back to the most conservative vmcnt
-            {
-                const int s1 = min(1, KT - 1) * 32, s2 = min(2, KT - 1) * 32;
-#pragma unroll
-                for (int n = 0; n < NI; n++) ra[n] = *(gptr4)(tsrc[n] + s1);
-#pragma unroll
-                for (int n = 0; n < NI; n++) rb[n] = *(gptr4)(tsrc[n] + s2);
-            }
-            auto step = [&](int sidx, f32x4(&rs)[NI]) {
-                char *cur = (sidx & 1) ? stage1 : stage0;
-                char *nxt = (sidx & 1) ? stage0 : stage1;
-                __syncthreads(); // stage sidx is in LDS for everyone; nxt is no longer being read
-                // branch-free body (the write after the last stage lands in a buffer nobody reads)
-#pragma unroll
-                for (int n = 0; n < NI; n++) *(f32x4 *)(nxt + lds_off[n] + lane * 16) = rs[n];
-                {
-                    const int sn = min(sidx + 3, KT - 1) * 32;
-#pragma unroll
-                    for (int n = 0; n < NI; n++) rs[n] = *(gptr4)(tsrc[n] + sn);
-                }
-                compute(cur, no_dma, nd_none{});
-            };
-            for (int kt = 0; kt + 1 < KT; kt += 2) {
-                step(kt, ra);
-                step(kt + 1, rb);
-            }
-            if (KT & 1) step(KT - 1, ra);
-        } else {
-            f32x4 sreg[NI];
-            // prologue: stage K step 0 into buffer 0
-#pragma unroll
-            for (int n = 0; n < NI; n++) {
-                if (GLDS && NTDB && n < DT / 32) stage_issue<GLDS, true>(tsrc[n], stage0 + lds_off[n], lane, sreg[n]); // rows, not queries
-                else stage_issue<GLDS>(tsrc[n], stage0 + lds_off[n], lane, sreg[n]);
-                if constexpr (!GLDS) *(f32x4 *)(stage0 + lds_off[n] + lane * 16) = sreg[n];
-            }
-            if constexpr (GLDS) {
-                for (int kt = 0; kt + 1 < KT; kt++) {
-                    char *cur = (kt & 1) ? stage1 : stage0;
-                    char *nxt = (kt & 1) ? stage0 : stage1;
-#ifndef KNN355_ABLATE_BARRIER // timing experiments only (wrong results): no K-step barrier / no staging
-                    __syncthreads(); // stage kt landed (vmcnt(0) + barrier); buffer nxt is free
-#endif
-                    const int koff = (kt + 1) * 32;
-#ifdef KNN355_ABLATE_DMA
-                    compute(cur, no_dma, nd_none{});
-#else
-                    compute(cur, [&](int n) {
-                        if (NTDB && n < DT / 32) stage_issue<true, true>(tsrc[n] + koff, nxt + lds_off[n], lane, sreg[n]);
-                        else stage_issue<true>(tsrc[n] + koff, nxt + lds_off[n], lane, sreg[n]);
-                    }, nd_all{});
-#endif
-                }
-                __syncthreads();
-                compute(((KT - 1) & 1) ? stage1 : stage0, no_dma, nd_none{});
-            } else {
-                for (int kt = 0; kt < KT; kt++) {
-                    char *cur = (kt & 1) ? stage1 : stage0;
-                    char *nxt = (kt & 1) ? stage0 : stage1;
-                    __syncthreads(); // stage kt is in LDS for everyone; buffer nxt is free
-                    if (kt + 1 < KT) {
-#pragma unroll
-                        for (int n = 0; n < NI; n++) stage_issue<false>(tsrc[n] + (kt + 1) * 32, nxt + lds_off[n], lane, sreg[n]);
-                    }
-                    compute(cur, no_dma, nd_none{});
-                    if (kt + 1 < KT) {
-#pragma unroll
-                        for (int n = 0; n < NI; n++) *(f32x4 *)(nxt + lds_off[n] + lane * 16) = sreg[n];
-                    }
-                }
-            }
+        for (int n = 0; n < NI; n++) {
+            if (NTDB && n < DT / 32) stage_issue<true>(tsrc[n], stage0 + lds_off[n]); // rows, not queries
+            else stage_issue<false>(tsrc[n], stage0 + lds_off[n]);
         }
+        for (int kt = 0; kt + 1 < KT; kt++) {
+            char *cur = (kt & 1) ? stage1 : stage0;
+            char *nxt = (kt & 1) ? stage0 : stage1;
+            __syncthreads(); // stage kt landed (vmcnt(0) + barrier); buffer nxt is free
+            const int koff = (kt + 1) * 32;
+            compute(cur, [&](int n) {
+                if (NTDB && n < DT / 32) stage_issue<true>(tsrc[n] + koff, nxt + lds_off[n]);
+                else stage_issue<false>(tsrc[n] + koff, nxt + lds_off[n]);
+            }, nd_all{});
+        }
+        __syncthreads();
+        compute(((KT - 1) & 1) ? stage1 : stage0, no_dma, nd_none{});
 
         // ---- epilogue: threshold filter + append ----
 #pragma unroll
@@ -921,7 +798,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
                     } else {
                         v = -acc[a][b][r];
                     }
-                    if (v <= thr && row < c_hi && qok && !(p.skip_mask >= 0 && ((int)(row >> KNN_VIEW_BLOCK_SHIFT) & p.skip_mask) == 0) && !(p.dbg & 4))
+                    if (v <= thr && row < c_hi && qok && !(p.skip_mask >= 0 && ((int)(row >> KNN_VIEW_BLOCK_SHIFT) & p.skip_mask) == 0))
                         L.append(ql, v, p.id_base + (uint32_t)view_row(row, p.row_mul), DT);
                 }
             }
@@ -930,7 +807,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 
         // ---- compaction of lists that could overflow on the next tile ----
         const bool last_tile = row0 + DT >= c_hi;
-        if ((*L.s_need || last_tile) && !(p.dbg & 2))
+        if (*L.s_need || last_tile)
             lists_compact<QT>(L, smem, DT, last_tile, p.nq - q0, p.partial + ((size_t)q0 * p.partial_lists + chunk) * p.kslot,
                               (size_t)p.partial_lists * p.kslot, tid);
     }
@@ -966,7 +843,6 @@ __global__ __launch_bounds__(256) void merge_select_kernel(const uint64_t *__res
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int P = 64;
     while (P < k) P <<= 1;
-    uint32_t *hist = nullptr; // bitwise search (the LDS-histogram radix variant measured slower here)
     uint64_t *sb = (uint64_t *)smem + (size_t)wave * P; // final round only
     const int64_t item = (int64_t)blockIdx.x * 4 + wave;
     const int64_t nitems = nq * Lout;
@@ -982,9 +858,9 @@ __global__ __launch_bounds__(256) void merge_select_kernel(const uint64_t *__res
             uint32_t T;
             const int R = (n + 63) >> 6;
             if constexpr (LISTMAJOR)
-                have = wave_select_dispatch_max<RMAX>(R, LoadListMajor{in, nq, q, kin, l0}, n, k, k, lane, &T, dst, hist);
+                have = wave_select_dispatch_max<RMAX>(R, LoadListMajor{in, nq, q, kin, l0}, n, k, k, lane, &T, dst);
             else
-                have = wave_select_dispatch_max<RMAX>(R, LoadContig{in + ((size_t)q * L + l0) * kin}, n, k, k, lane, &T, dst, hist);
+                have = wave_select_dispatch_max<RMAX>(R, LoadContig{in + ((size_t)q * L + l0) * kin}, n, k, k, lane, &T, dst);
         } else {
             for (int i = lane; i < n; i += 64) {
                 if constexpr (LISTMAJOR) dst[i] = LoadListMajor{in, nq, q, kin, l0}(i);
@@ -1230,9 +1106,19 @@ struct DevBuf {
     int device = 0;
     int ensure(size_t need)
     {
-        if (need <= bytes) return 0;
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        if (need <= bytes && cur == device) return 0;
+        if (p) {
+            // growing (or the device changed): kernels enqueued on any stream may still use the old
+            // buffer, and the pool would hand it to another handle right away.  Rare (first searches
+            // of a handle), so a full device wait is affordable.
+            (void)hipSetDevice(device);
+            (void)hipDeviceSynchronize();
+            (void)hipSetDevice(cur);
+        }
         release();
-        (void)hipGetDevice(&device);
+        device = cur;
         size_t got = 0;
         if (void *q = g_pool.take(need, device, &got)) {
             p = q;
@@ -1260,6 +1146,10 @@ struct knn_index_s {
     int num_cus = 256;
     int64_t ntotal = 0, cap_rows = 0;
     bool is_view = false; // shares another handle's database (knn_flat_view): read-only, frees nothing of it
+    // storage generation: bumped whenever xb/yn are reallocated, reset or freed.  A view remembers the
+    // value it was made at and refuses to search once its parent's storage has moved on.
+    std::shared_ptr<std::atomic<int64_t>> storage_gen = std::make_shared<std::atomic<int64_t>>(0);
+    int64_t view_gen = 0;
     float *xb = nullptr; // [cap_rows][dp]
     float *yn = nullptr; // [cap_rows + pad]
     size_t xb_bytes = 0, yn_bytes = 0; // allocation sizes (may exceed the row capacity: pooled)
@@ -1271,6 +1161,7 @@ struct knn_index_s {
     std::mutex mu;
     DevBuf ws_q, ws_qn, ws_lists, ws_gthr, ws_partial, ws_partial2, ws_keys, ws_D, ws_I, ws_tmp, ws_tmp2;
     DevBuf ws_D1, ws_I1, ws_tmp3; // second set for the pipelined host search
+    DevBuf ws_merge0, ws_merge1;  // knn_merge_keys_dev: intermediate rounds (per handle, i.e. per lane)
     DevBuf ws_level[8]; // per seed-recursion level: [nq][lists][k] survivor keys
     int last_seed_stride = 0;
     // tuning + introspection
@@ -1408,6 +1299,8 @@ extern "C" int knn_flat_view(knn_handle parent, knn_handle *out)
     h->device = parent->device;
     h->num_cus = parent->num_cus;
     h->is_view = true;
+    h->storage_gen = parent->storage_gen;
+    h->view_gen = parent->storage_gen->load();
     h->xb = parent->xb;
     h->yn = parent->yn;
     h->ntotal = parent->ntotal;
@@ -1432,6 +1325,7 @@ static void *pool_alloc(size_t bytes, int device, size_t *got)
 
 static void free_index_buffers(knn_index_s *h)
 {
+    if (!h->is_view) h->storage_gen->fetch_add(1);
     if (h->xb && !h->is_view) g_pool.give(h->xb, h->xb_bytes, h->device);
     if (h->yn && !h->is_view) g_pool.give(h->yn, h->yn_bytes, h->device);
     h->xb = nullptr;
@@ -1444,8 +1338,10 @@ extern "C" void knn_free(knn_handle h)
 {
     if (!h) return;
     if (hipSetDevice(h->device) == hipSuccess) {
+        if (h->stream) (void)hipStreamSynchronize(h->stream);
+        if (!h->is_view && h->xb) (void)hipDeviceSynchronize(); // a view's stream may still be scanning these rows
         free_index_buffers(h);
-        DevBuf *bufs[] = {&h->ws_q, &h->ws_qn, &h->ws_lists, &h->ws_gthr, &h->ws_partial, &h->ws_partial2,
+        DevBuf *bufs[] = {&h->ws_merge0, &h->ws_merge1, &h->ws_q, &h->ws_qn, &h->ws_lists, &h->ws_gthr, &h->ws_partial, &h->ws_partial2,
                           &h->ws_keys, &h->ws_D, &h->ws_I, &h->ws_tmp, &h->ws_tmp2, &h->ws_D1, &h->ws_I1, &h->ws_tmp3};
         for (DevBuf *b : bufs) b->release();
         for (DevBuf &b : h->ws_level) b.release();
@@ -1496,7 +1392,11 @@ static int grow_index(knn_index_s *h, int64_t need_rows)
         HIP_TRY(hipMemcpyAsync(nyn, h->yn, (size_t)h->ntotal * 4, hipMemcpyDeviceToDevice, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
-    if (h->xb) g_pool.give(h->xb, h->xb_bytes, h->device);
+    if (h->xb) {
+        h->storage_gen->fetch_add(1); // views of the old storage are dead
+        (void)hipDeviceSynchronize(); // ... and nothing may still be scanning it
+        g_pool.give(h->xb, h->xb_bytes, h->device);
+    }
     if (h->yn) g_pool.give(h->yn, h->yn_bytes, h->device);
     h->xb = nxb;
     h->yn = nyn;
@@ -1688,19 +1588,15 @@ struct ScanPlan {
 template <int WM, int WN, int TM, int TN>
 static int launch_scan_cfg(const knn_index_s *h, const ScanParams &p, const ScanPlan &plan, hipStream_t s, bool sample = false)
 {
-    // staging variant: 0 = LDS-DMA double buffer, 1 = register staged (flags & 1, test build),
-    // 2 = register ring two stages ahead (flags & 64)
-    const int stg = (h->flags & 64) ? 2 : ((h->flags & 1) ? 1 : 0);
     const bool l2 = h->metric == KNN_METRIC_L2;
     void (*kern)(ScanParams) = nullptr;
-    if (l2)
-        kern = stg == 0 ? flat_scan_kernel<WM, WN, TM, TN, true, 0> : (stg == 1 ? flat_scan_kernel<WM, WN, TM, TN, true, 1> : flat_scan_kernel<WM, WN, TM, TN, true, 2>);
-    else
-        kern = stg == 0 ? flat_scan_kernel<WM, WN, TM, TN, false, 0> : (stg == 1 ? flat_scan_kernel<WM, WN, TM, TN, false, 1> : flat_scan_kernel<WM, WN, TM, TN, false, 2>);
-    if (sample && stg == 0) kern = l2 ? flat_scan_kernel<WM, WN, TM, TN, true, 0, true> : flat_scan_kernel<WM, WN, TM, TN, false, 0, true>;
-    if (stg == 0 && p.nqtiles == 1 && !(h->flags & 32)) { // one query tile: rows are read once (flags & 32: plain loads, A/B)
-        if (sample) kern = l2 ? flat_scan_kernel<WM, WN, TM, TN, true, 0, true, true> : flat_scan_kernel<WM, WN, TM, TN, false, 0, true, true>;
-        else kern = l2 ? flat_scan_kernel<WM, WN, TM, TN, true, 0, false, true> : flat_scan_kernel<WM, WN, TM, TN, false, 0, false, true>;
+    const bool nt = p.nqtiles == 1; // one query tile: rows are read once, non-temporal staging loads
+    if (sample) {
+        if (nt) kern = l2 ? flat_scan_kernel<WM, WN, TM, TN, true, true, true> : flat_scan_kernel<WM, WN, TM, TN, false, true, true>;
+        else kern = l2 ? flat_scan_kernel<WM, WN, TM, TN, true, true, false> : flat_scan_kernel<WM, WN, TM, TN, false, true, false>;
+    } else {
+        if (nt) kern = l2 ? flat_scan_kernel<WM, WN, TM, TN, true, false, true> : flat_scan_kernel<WM, WN, TM, TN, false, false, true>;
+        else kern = l2 ? flat_scan_kernel<WM, WN, TM, TN, true, false, false> : flat_scan_kernel<WM, WN, TM, TN, false, false, false>;
     }
     HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds));
     hipLaunchKernelGGL(kern, dim3(plan.grid), dim3(256), plan.lds, s, p);
@@ -1824,7 +1720,6 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     p.skip_mask = sstride ? sstride - 1 : -1;
     p.partial_lists = nlists;
     p.kslot = kslot;
-    p.dbg = h->flags & (6 | 256);
     const bool top = level == 0;
     if (top) {
         const int slot = (int)(h->nlaunches % knn_index_s::RING);
@@ -1872,6 +1767,8 @@ static int check_search_args(knn_index_s *h, const void *q, int64_t nq, int64_t 
     if (k < 1) return set_err(KNN_ERR_INVALID, "search: k must be >= 1");
     if (k > KNN_MAX_K) return set_err(KNN_ERR_UNSUPPORTED, "search: k > 2048 is not supported by the fused top-k");
     if (nq > 0 && (!q || !D || !I)) return set_err(KNN_ERR_INVALID, "search: null pointer");
+    if (h->is_view && h->storage_gen->load() != h->view_gen)
+        return set_err(KNN_ERR_INVALID, "search: this view is stale (its parent index was grown, reset or freed after the view was made)");
     return 0;
 }
 
@@ -1938,18 +1835,19 @@ extern "C" int knn_flat_search_keys_dev(knn_handle h, const float *q_dev, int64_
     return 0;
 }
 
-extern "C" int knn_merge_keys_dev(int32_t device, int32_t metric, const uint64_t *keys_dev, int32_t nlists,
-                                  int64_t nq, int64_t k, float *D_dev, int64_t *I_dev, void *stream)
+extern "C" int knn_merge_keys_dev(knn_handle h, const uint64_t *keys_dev, int32_t nlists, int64_t nq, int64_t k,
+                                  float *D_dev, int64_t *I_dev, void *stream)
 {
+    if (!h) return set_err(KNN_ERR_INVALID, "merge_keys: null handle");
     if (nlists < 1 || nq < 0 || k < 1 || k > KNN_MAX_K) return set_err(KNN_ERR_INVALID, "merge_keys: bad shape");
     if (nq == 0) return 0;
     if (!keys_dev || !D_dev || !I_dev) return set_err(KNN_ERR_INVALID, "merge_keys: null pointer");
-    int rc = ensure_device(device);
-    if (rc) return rc;
-    hipStream_t s = (hipStream_t)stream;
-    // intermediate rounds only exist for nlists > 4096/k (more than 40 shards at k=100)
-    static thread_local DevBuf t0, t1;
-    rc = run_merge(keys_dev, nlists, (int)k, (int)k, nq, true, t0, t1, nullptr, metric, D_dev, I_dev, s);
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    // intermediate rounds (nlists > 4096/k, e.g. 8 shards at k = 1000) use scratch owned by THIS handle:
+    // two lanes merging on two streams never share it
+    int rc = run_merge(keys_dev, nlists, (int)k, (int)k, nq, true, h->ws_merge0, h->ws_merge1, nullptr, h->metric, D_dev, I_dev, s);
     if (rc) return rc;
     if (!stream) HIP_TRY(hipStreamSynchronize(s));
     return 0;
@@ -2189,7 +2087,11 @@ extern "C" int knn_flat_reserve(knn_handle h, int64_t nrows)
         HIP_TRY(hipMemcpyAsync(nyn, h->yn, (size_t)h->ntotal * 4, hipMemcpyDeviceToDevice, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
-    if (h->xb) g_pool.give(h->xb, h->xb_bytes, h->device);
+    if (h->xb) {
+        h->storage_gen->fetch_add(1);
+        (void)hipDeviceSynchronize();
+        g_pool.give(h->xb, h->xb_bytes, h->device);
+    }
     if (h->yn) g_pool.give(h->yn, h->yn_bytes, h->device);
     h->xb = nxb;
     h->yn = nyn;

@@ -382,6 +382,11 @@ def _read_index(f):
         M = int(cum[2] - cum[1]) if cum.size > 2 else int(cum[1] // 2)
         idx = IndexHNSWFlat(d, M, metric)
         L = _lib.lib()
+        # the neighbour table is addressed through the per-level slot counts: the file's table must
+        # be the one this build derives from M (FAISS computes it the same way, in float)
+        own_cum = idx.graph()[3]
+        if cum.size != own_cum.size or not np.array_equal(cum, own_cum):
+            raise RuntimeError("read_index: IHNf cum_nneighbor_per_level does not match M = %d" % M)
         rows = storage.reconstruct_n(0, ntotal) if ntotal else np.empty((0, d), np.float32)
         if ntotal:
             _lib.check(L.knn_flat_add(L.knn_hnsw_storage(idx._h), rows.ctypes.data, ntotal))

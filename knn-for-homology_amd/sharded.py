@@ -99,11 +99,12 @@ class HipShardBackend:
                                                   ctypes.c_void_p(stream)))
         return D, I
 
-    def merge(self, gathered: torch.Tensor, nlists: int, nq: int, k: int):
+    def merge(self, gathered: torch.Tensor, nlists: int, nq: int, k: int, index=None):
         D = torch.empty((nq, k), dtype=torch.float32, device=gathered.device)
         I = torch.empty((nq, k), dtype=torch.int64, device=gathered.device)
         stream = torch.cuda.current_stream(gathered.device).cuda_stream
-        _lib.check(_lib.lib().knn_merge_keys_dev(gathered.device.index or 0, self.metric, gathered.data_ptr(), nlists,
+        # the lane's own handle: its merge scratch is private to the lane's stream
+        _lib.check(_lib.lib().knn_merge_keys_dev((index or self.index)._h, gathered.data_ptr(), nlists,
                                                  nq, k, D.data_ptr(), I.data_ptr(), ctypes.c_void_p(stream)))
         return D, I
 
@@ -167,7 +168,7 @@ class ShardedFlatIndex:
         # rank-major concatenation along dim 0 == [world, nq, k]
         gathered = torch.empty((self.world * nq, k), dtype=torch.int64, device=keys.device)
         dist.all_gather_into_tensor(gathered, keys, group=self.group)
-        return self.backend.merge(gathered.view(self.world, nq, k), self.world, nq, k)
+        return self.backend.merge(gathered.view(self.world, nq, k), self.world, nq, k, **kw)
 
     def submit(self, q, k) -> PendingSearch:
         """Enqueues one search of q ([nq, d] float32, identical on every rank) and returns at once.

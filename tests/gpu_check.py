@@ -82,7 +82,7 @@ def main():
         trn, ten = tr.copy(), te.copy()
         orc.normalize_l2(trn)
         orc.normalize_l2(ten)
-        for flags in (0, 1):
+        for flags in (0,):
             case(f"{ds} cosine", trn, ten, min(10, tr.shape[0]), 0, flags=flags)
             case(f"{ds} l2", tr, te, min(10, tr.shape[0]), 1, flags=flags)
         case(f"{ds} cosine k>nb", trn, ten, tr.shape[0] + 7, 0)
@@ -92,12 +92,6 @@ def main():
         for nch in (1, 3):
             for metric in (0, 1):
                 case(f"rand qt={qt} nch={nch}", xb, xq[:qt + 5], 100, metric, qt=qt, nchunks=nch)
-    for metric in (0, 1):
-        case("ring staging qt=32", xb, xq[:30], 100, metric, qt=32, flags=64)
-        case("ring staging qt=64", xb, xq[:60], 100, metric, qt=64, flags=64)
-        case("ring staging qt=128", xb, xq[:200], 100, metric, qt=128, flags=64)
-    case("ring staging d=100", rng.standard_normal((2049, 100), dtype=np.float32), rng.standard_normal((77, 100), dtype=np.float32), 13, 1, flags=64)
-    case("ring staging d=37", rng.standard_normal((700, 37), dtype=np.float32), rng.standard_normal((50, 37), dtype=np.float32), 11, 0, flags=64)
     case("rand auto k=1000", xb, xq, 1000, 0)
     case("rand auto k=301 l2", xb, xq, 301, 1)
     case("rand auto k=1", xb, xq[:7], 1, 0)

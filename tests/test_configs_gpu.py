@@ -1,0 +1,247 @@
+"""GPU: BASELINE.json configs and entry points that round 1 left unexercised ("next" item 1):
+  (a) configs[4]  HNSW M=32 / efSearch=256 at 200 000 x 1024, recall@100 vs flat
+  (b) configs[2]  flat L2 k=100 at 200 000 x 1024 through search_self AND search(x)
+  (c) cath.search.search_and_save file protocol        (cath/search.py:29-53)
+  (d) seqvec_search.main.main CLI incl. --knn-index    (seqvec_search/main.py:112-136)
+  (e) pfam.proteins_search.main in lsh mode            (pfam/proteins_search.py:25-26)
+  (f) knn_gather_distances against the oracle's pair distances
+  (g) the real faiss, when the box happens to have it  (last row)
+"""
+import ctypes
+import logging
+import shutil
+import time
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, DATASETS
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def _assert_same(D, I, Do, Io):
+    assert np.array_equal(I, Io), f"{int((I != Io).sum())} neighbour ids differ"
+    assert np.array_equal(_bits(D), _bits(Do)), f"{int((_bits(D) != _bits(Do)).sum())} distances differ"
+
+
+def _pfam_like(n, d, seed_c=21, seed_x=22, ncent=2000):
+    """SURVEY 8(d) S-pfam: clustered rows, centre + 0.35 * noise."""
+    cent = np.random.default_rng(seed_c).standard_normal((ncent, d)).astype(np.float32)
+    rng = np.random.default_rng(seed_x)
+    x = cent[rng.integers(0, ncent, n)]
+    x += 0.35 * rng.standard_normal((n, d), dtype=np.float32)
+    return x, rng
+
+
+# ---- (a) ---------------------------------------------------------------------------------
+def test_hnsw_config5_200k(gpu_faiss, capsys):
+    """BASELINE configs[4]: Pfam-subset-sized HNSW (M=32, efSearch=256), recall@100 against the exact
+    flat search of the same rows; every returned distance is the flat kernel's value for that pair."""
+    n, d, nq, k = 200_000, 1024, 2000, 100
+    x, rng = _pfam_like(n, d)
+    gpu_faiss.normalize_L2(x)
+    qsel = rng.choice(n, nq, replace=False)
+    q = np.ascontiguousarray(x[qsel])
+    flat = gpu_faiss.IndexFlat(d, gpu_faiss.METRIC_INNER_PRODUCT)
+    flat.add(x)
+    Dt, It = flat.search(q, k)
+    idx = gpu_faiss.IndexHNSWFlat(d, 32, gpu_faiss.METRIC_INNER_PRODUCT)
+    t0 = time.time()
+    idx.add(x)
+    build_s = time.time() - t0
+    idx.hnsw.efSearch = 256
+    idx.search(q[:64], k)  # warm-up
+    t0 = time.time()
+    D, I = idx.search(q, k)
+    search_s = time.time() - t0
+    recall = sum(len(np.intersect1d(a[a >= 0], b)) for a, b in zip(I, It)) / It.size
+    with capsys.disabled():
+        print(f"\n[hnsw 200k x 1024, M=32, efSearch=256, k=100] build {build_s:.2f}s, {nq / search_s:.0f} queries/s, "
+              f"recall@100 vs flat {recall:.4f}")
+    assert idx.ntotal == n and recall >= 0.95
+    assert (np.diff(D, axis=1) <= 0).all()
+    # a query is a database row: it finds itself first, with the flat search's score
+    assert (I[:, 0] == qsel).mean() > 0.99
+    ref = [dict(zip(It[r].tolist(), _bits(Dt[r]).tolist())) for r in range(64)]
+    for r in range(64):
+        for j, v in zip(I[r].tolist(), _bits(D[r]).tolist()):
+            if j in ref[r]:
+                assert ref[r][j] == v
+
+
+# ---- (b) ---------------------------------------------------------------------------------
+def test_config2_flat_l2_k100_200k(gpu_faiss, oracle):
+    """BASELINE configs[2] as worded: flat L2, k=100, 200 000 x 1024 all-vs-all -- once with the rows as
+    their own queries (search_self, the entry points' path) and once through index.search(x) (queries
+    uploaded in pipelined batches of 16384).  Same bits both ways; oracle bits on sampled rows."""
+    n, d, k = 200_000, 1024, 100
+    x, rng = _pfam_like(n, d, 31, 32)
+    idx = gpu_faiss.IndexFlat(d, gpu_faiss.METRIC_L2)
+    idx.add(x)
+    D, I = idx.search_self(k)
+    assert idx.last_scan()["kernel"] == "flat_scan_q128_d128"
+    assert D.shape == (n, k) and (np.diff(D, axis=1) >= 0).all() and I.min() >= 0 and I.max() < n
+    assert (I[:, 0] == np.arange(n)).all() and (D[:, 0] == 0).all(), "self hit first at distance exactly 0"
+    D2, I2 = idx.search(x, k)
+    _assert_same(D2, I2, D, I)
+    sample = rng.choice(n, 16, replace=False)
+    Do, Io = oracle.flat_search(x, x[sample], k, 1)
+    _assert_same(D[sample], I[sample], Do, Io)
+
+
+# ---- (c) ---------------------------------------------------------------------------------
+def test_search_and_save_protocol(gpu_faiss, oracle, tmp_path, capsys):
+    """cath/search.py:29-53: both metrics x every *.npy of the directory (fp16 files cast to fp32, any
+    embedder width), '<stem>.<metric>-search-time.txt', hits_/scores_<metric>.npz keyed by file stem."""
+    from knn_for_homology_amd.cath.search import search_and_save
+    rng = np.random.default_rng(3)
+    a = np.load(GOLDEN / "pfam-20-dist" / "train.npy").astype(np.float16)   # fp16, d = 1024
+    b = rng.standard_normal((150, 1280), dtype=np.float32)                   # fp32, d = 1280 (ESM width)
+    np.save(tmp_path / "prottrans_t5.npy", a)
+    np.save(tmp_path / "esm.npy", b)
+    search_and_save(tmp_path)
+    out = capsys.readouterr().out
+    assert "Searching with Cosine" in out and "Searching with Euclidean" in out
+    assert f"prottrans_t5 {a.shape}" in out and f"esm {b.shape}" in out
+    for label, metric in (("cosine", 0), ("euclidean", 1)):
+        hits = np.load(tmp_path / f"hits_{label}.npz")
+        scores = np.load(tmp_path / f"scores_{label}.npz")
+        assert sorted(hits.files) == ["esm", "prottrans_t5"] and sorted(scores.files) == ["esm", "prottrans_t5"]
+        for stem, arr in (("prottrans_t5", a), ("esm", b)):
+            t = float((tmp_path / f"{stem}.{label}-search-time.txt").read_text())
+            assert t >= 0
+            x = arr.astype(np.float32)
+            if metric == 0:
+                oracle.normalize_l2(x)
+            Do, Io = oracle.flat_search(x, x, 11, metric)
+            assert hits[stem].dtype == np.int64 and scores[stem].dtype == np.float32
+            _assert_same(scores[stem], hits[stem], Do[:, 1:], Io[:, 1:])
+
+
+# ---- (d) ---------------------------------------------------------------------------------
+def test_main_cli_with_and_without_index(gpu_faiss, tmp_path, caplog):
+    """seqvec_search/main.py:112-136: `main dataset` searches train.npy, `main dataset --knn-index f` searches a
+    stored index; both give the reference's known answer on pfam-20-10 (tests/test_main.py:21-27)."""
+    from knn_for_homology_amd.seqvec_search import main as m
+    ds = tmp_path / "pfam-20-10"
+    shutil.copytree(GOLDEN / "pfam-20-10", ds)
+    with caplog.at_level(logging.INFO):
+        results, scores, auc1s, tps = m.main([str(ds), "--hits", "10"])
+    assert results.shape == (200, 10) and np.mean(auc1s) == 0.871 and np.mean(tps) == 0.91
+    assert any("Mean AUC1 for k-NN: 0.871000, Mean TP: 0.910000" in r.getMessage() for r in caplog.records)
+    # a stored flat inner-product index of the normalised training rows
+    train = np.load(ds / "train.npy")
+    gpu_faiss.normalize_L2(train)
+    index = gpu_faiss.IndexFlat(1024, gpu_faiss.METRIC_INNER_PRODUCT)
+    index.add(train)
+    f = tmp_path / "knn.index"
+    gpu_faiss.write_index(index, str(f))
+    r2, s2, auc2, tps2 = m.main([str(ds), "--knn-index", str(f), "--hits", "10"])
+    _assert_same(s2, r2, scores, results)
+    assert auc2 == auc1s and tps2 == tps
+    r3 = m.main([str(ds)])[0]  # --hits defaults to seqvec_search/constants.py default_hits
+    assert r3.shape == (200, 13) and np.array_equal(r3[:, :10], results)
+    with pytest.raises(SystemExit):
+        m.main([])  # dataset is required
+
+
+# ---- (e) ---------------------------------------------------------------------------------
+def test_proteins_search_lsh_mode(gpu_faiss, tmp_path, capsys):
+    """pfam/proteins_search.py:25-26: the third index mode, IndexLSH(d, 2048), end to end."""
+    from knn_for_homology_amd.pfam import proteins_search
+    x = np.load(GOLDEN / "pfam-20-dist" / "test.npy")
+    np.save(tmp_path / "full_sequences.npy", x)
+    proteins_search.main(["prog", "lsh"], data_dir=tmp_path, k=30)
+    out = capsys.readouterr().out
+    assert "Index creation took" in out and "Search took" in out and "Difference:" in out
+    scores = np.load(tmp_path / "full_sequences_lsh_scores.npy")
+    hits = np.load(tmp_path / "full_sequences_lsh_hits.npy")
+    assert scores.shape == (210, 30) and scores.dtype == np.float32 and hits.dtype == np.int64
+    assert (hits[:, 0] == np.arange(210)).all() and (scores[:, 0] == 0).all(), "a row's own code is at Hamming distance 0"
+    assert (np.diff(scores, axis=1) >= 0).all() and (scores == np.round(scores)).all() and scores.max() <= 2048
+    # the index file holds 2048-bit codes: 256 bytes per row plus the rotation
+    size = (tmp_path / "full_sequences_lsh.index").stat().st_size
+    assert size > 210 * 256
+    back = gpu_faiss.read_index(str(tmp_path / "full_sequences_lsh.index"))
+    xn = x.astype(np.float32)
+    gpu_faiss.normalize_L2(xn)
+    D2, I2 = back.search(xn, 30)
+    assert np.array_equal(I2, hits) and np.array_equal(D2, scores)
+
+
+# ---- (f) ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("metric", [0, 1])
+def test_gather_distances_matches_oracle(gpu_faiss, oracle, metric):
+    """knn_gather_distances (explicit candidate lists, the HNSW offload entry of the C ABI): the same fp32
+    chain as the flat scan -- bits equal the oracle's pair distances and the flat search's D."""
+    from knn_for_homology_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(17 + metric)
+    nb, d, nq = 5000, 1024, 9
+    xb = rng.standard_normal((nb, d), dtype=np.float32)
+    xq = rng.standard_normal((nq, d), dtype=np.float32)
+    idx = gpu_faiss.IndexFlat(d, metric)
+    idx.add(xb)
+    counts = np.array([0, 1, 64, 100, 7, 0, 333, 2, 50])
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    cand = rng.integers(0, nb, offs[-1]).astype(np.int64)
+    out = np.full(offs[-1], np.nan, np.float32)
+    _lib.check(L.knn_gather_distances(idx._h, xq.ctypes.data, nq, cand.ctypes.data, offs.ctypes.data, out.ctypes.data))
+    qidx = np.repeat(np.arange(nq), counts).astype(np.int32)
+    want = oracle.pair_distances(xb, xq, qidx, cand, metric)
+    assert np.array_equal(_bits(out), _bits(want))
+    # ... which are the flat search's distances for those pairs
+    D, I = idx.search(xq, 2048)
+    for i in (2, 3, 6):
+        ref = dict(zip(I[i].tolist(), _bits(D[i]).tolist()))
+        for c, v in zip(cand[offs[i]:offs[i + 1]].tolist(), _bits(out[offs[i]:offs[i + 1]]).tolist()):
+            if c in ref:
+                assert ref[c] == v
+    # errors: candidate out of range, offsets not monotone
+    bad = cand.copy()
+    bad[3] = nb
+    assert L.knn_gather_distances(idx._h, xq.ctypes.data, nq, bad.ctypes.data, offs.ctypes.data, out.ctypes.data) != 0
+    boffs = offs.copy()
+    boffs[2] = 0
+    assert L.knn_gather_distances(idx._h, xq.ctypes.data, nq, cand.ctypes.data, boffs.ctypes.data, out.ctypes.data) != 0
+
+
+# ---- (g) ---------------------------------------------------------------------------------
+def test_against_real_faiss_if_importable(gpu_faiss, ko):
+    """faiss-cpu is not installable in the build container (no network) and does not travel to the GPU box, so raw
+    id / bit parity with FAISS itself is pinned only through the reference's known answers.  The day the real module
+    is importable this test compares directly: ids equal wherever fp32 noise cannot reorder them, distances within
+    the north star's 1e-5."""
+    faiss = pytest.importorskip("faiss", reason="the real faiss module is not installed on this box")
+    for ds in DATASETS:
+        train = np.load(GOLDEN / ds / "train.npy")
+        test = np.load(GOLDEN / ds / "test.npy")
+        for metric in (0, 1):
+            tr, te = train.copy(), test.copy()
+            if metric == 0:
+                faiss.normalize_L2(tr)
+                faiss.normalize_L2(te)
+                a, b = train.copy(), test.copy()
+                gpu_faiss.normalize_L2(a)
+                gpu_faiss.normalize_L2(b)
+                assert np.abs(a - tr).max() <= 1e-6
+            k = min(10, tr.shape[0])
+            ref = faiss.IndexFlat(tr.shape[1], faiss.METRIC_INNER_PRODUCT if metric == 0 else faiss.METRIC_L2)
+            ref.add(tr)
+            Dr, Ir = ref.search(te, k)
+            ours = gpu_faiss.IndexFlat(tr.shape[1], metric)
+            ours.add(tr)
+            D, I = ours.search(te, k)
+            # both within fp32 noise of the fp64 truth (ids may only permute inside near-tie clusters) ...
+            ko.compare_tie_tolerant(I, D, tr, te, metric)
+            ko.compare_tie_tolerant(Ir, Dr, tr, te, metric)
+            # ... and against each other: distances within the north star's 1e-5 (relative to the magnitudes the
+            # fp32 sums are formed from), ids identical except inside such clusters
+            scale = 1.0 if metric == 0 else float((tr.astype(np.float64) ** 2).sum(1).max() + (te.astype(np.float64) ** 2).sum(1).max())
+            assert np.abs(D.astype(np.float64) - Dr).max() <= 1e-5 * max(1.0, scale)
+            assert (I == Ir).mean() >= 0.99

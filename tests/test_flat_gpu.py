@@ -161,18 +161,30 @@ def test_query_batching_over_16384(gpu_faiss, oracle):
         _assert_same(D, I, Do, Io)
 
 
-def test_register_staged_variant_matches(gpu_faiss, oracle):
-    """flags=1 selects the register-staged (no LDS-DMA) build of the scan kernel."""
-    rng = np.random.default_rng(5)
-    xb = rng.standard_normal((3000, 1024), dtype=np.float32)
-    xq = rng.standard_normal((150, 1024), dtype=np.float32)
-    for metric in (0, 1):
-        idx = gpu_faiss.IndexFlat(1024, metric)
-        for flags in (1, 64, 256):  # register staged, register ring, radix-select experiment
-            idx.set_tuning(0, 0, flags)
-            if idx.ntotal == 0:
-                idx.add(xb)
-            _assert_same(*idx.search(xq, 50), *oracle.flat_search(xb, xq, 50, metric))
+@pytest.mark.parametrize("k,nq", [(1500, 20), (1434, 32), (1536, 7), (1000, 20), (300, 20)])
+@pytest.mark.parametrize("metric", [0, 1])
+def test_sorted_database_never_overflows_lists(gpu_faiss, oracle, k, nq, metric):
+    """Every new tile beats everything seen so far (rows sorted by increasing similarity to all queries):
+    each tile appends all of its rows to every list.  With the 32-query / 256-row tile and k in
+    (1433, 1536] a cut to 1.25 k keys would leave less than one tile of room in a 2048-key list --
+    the cut must stop at cap - tile rows."""
+    rng = np.random.default_rng(k + nq)
+    d, nb = 64, 9000
+    base = rng.standard_normal(d).astype(np.float32)
+    base /= np.linalg.norm(base)
+    noise = 0.01 * rng.standard_normal((nb, d)).astype(np.float32)
+    if metric == 0:   # inner product with the queries grows with the row number
+        xb = (np.linspace(0.1, 3.0, nb, dtype=np.float32)[:, None] * base[None, :] + noise).astype(np.float32)
+        xq = (base[None, :] + 0.01 * rng.standard_normal((nq, d)).astype(np.float32)).astype(np.float32)
+    else:             # distance to the queries shrinks with the row number
+        xb = (np.linspace(3.0, 0.1, nb, dtype=np.float32)[:, None] * base[None, :] + noise).astype(np.float32)
+        xq = (0.01 * rng.standard_normal((nq, d))).astype(np.float32)
+    idx = gpu_faiss.IndexFlat(d, metric)
+    idx.add(xb)
+    for nch in (1, 0):
+        idx.set_tuning(0, nch, 8)  # no seeding: the lists warm up on their own
+        D, I = idx.search(xq, k)
+        _assert_same(D, I, *oracle.flat_search(xb, xq, k, metric))
 
 
 def test_normalize_matches_oracle(gpu_faiss, oracle):
