@@ -202,7 +202,10 @@ int knn_eval_levels(const int64_t *hits, int64_t nq, int64_t k, const int64_t *q
 /* ---- MMseqs2 prefilter database: SURVEY section 8(f) N3 ----------------------------
  * seqvec_search/mmseqs/_write_prefilter_db.py:52-97 write_prefilter_db: data file
  * ("<prefilter>.0") and index file ("<prefilter>.index"); queries[i] is the faiss row of
- * query i, *_map translate faiss rows to MMseqs2 ids; clip as in the reference. */
+ * query i, *_map translate faiss rows to MMseqs2 ids.  clip: 0 = the reference's clip=False
+ * (scores * 100 in float32); 1 = clip=True as the reference's pinned numpy 1.22 evaluates
+ * numpy.clip(scores, -(10**30), 10**30) * 100 (in double); 2 = clip=True under numpy >= 2
+ * (NEP 50: the expression stays float32). */
 int knn_write_prefilter_db(const char *data_path, const char *index_path, const int64_t *hits,
                            const float *scores, int64_t nq, int64_t k, const int64_t *queries,
                            const int64_t *test_map, int64_t n_test, const int64_t *train_map,

@@ -5,7 +5,9 @@ the next bottleneck after the search at k = 300, N = 200k).
 Format (reference lines 66-97): ``<db>.dbtype`` = 07 00 00 00; ``<db>.0`` holds per query the
 lines ``<target mmseqs id>\\t<int(score*100)>\\t0\\n`` (hits equal to -1 skipped) followed by a
 NUL byte; ``<db>.index`` holds ``<query mmseqs id>\\t<offset>\\t<length>\\n`` per query.
-Formatting runs natively (libknn355, OpenMP) and writes the same bytes.
+Formatting runs natively (libknn355, OpenMP) and writes the same bytes -- the bytes the reference
+writes under the caller's numpy: ``numpy.clip(scores, -(10**30), 10**30) * 100`` (line 75) is
+evaluated in double by numpy 1.x (the reference pins 1.22.2) and in float32 by numpy >= 2.
 """
 import logging
 from pathlib import Path
@@ -47,4 +49,10 @@ def write_prefilter_db(hits: ndarray, prefilter_db: Path, queries: ndarray, scor
     _lib.check(_lib.lib().knn_write_prefilter_db(
         str(prefilter_db.with_suffix(".0")).encode(), str(prefilter_db.with_suffix(".index")).encode(),
         hits.ctypes.data, scores.ctypes.data, hits.shape[0], hits.shape[1], queries.ctypes.data,
-        tmap.ctypes.data, tmap.shape[0], rmap.ctypes.data, rmap.shape[0], 1 if clip else 0))
+        tmap.ctypes.data, tmap.shape[0], rmap.ctypes.data, rmap.shape[0], _clip_mode(clip)))
+
+
+def _clip_mode(clip: bool) -> int:
+    if not clip:
+        return 0
+    return 2 if int(numpy.__version__.split(".")[0]) >= 2 else 1

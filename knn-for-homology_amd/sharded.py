@@ -140,6 +140,9 @@ class ShardedFlatIndex:
         # exercise the keys -> all-gather -> merge path even with one rank (tests)
         self.force_collective = os.environ.get("KNN355_FORCE_COLLECTIVE", "0") == "1"
         self.backend = backend if backend is not None else HipShardBackend(d, metric)
+        # a list here makes every search append a (start, end) pair of timing events recorded on the lane's
+        # stream around its all-gather (bench.py reports their mean)
+        self.collective_events = None
 
     @property
     def local(self):
@@ -167,7 +170,14 @@ class ShardedFlatIndex:
         keys = self.backend.search_keys(q, k, self.row_offset, **kw)
         # rank-major concatenation along dim 0 == [world, nq, k]
         gathered = torch.empty((self.world * nq, k), dtype=torch.int64, device=keys.device)
+        timed = self.collective_events is not None and keys.is_cuda
+        if timed:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         dist.all_gather_into_tensor(gathered, keys, group=self.group)
+        if timed:
+            ev1.record()
+            self.collective_events.append((ev0, ev1))
         return self.backend.merge(gathered.view(self.world, nq, k), self.world, nq, k, **kw)
 
     def submit(self, q, k) -> PendingSearch:

@@ -78,12 +78,17 @@ def compute_tps_comulative(ids_to_family, train_ids, test_ids, results):
     return (is_correct.cumsum(axis=1) / expanded).mean(axis=0)
 
 
-def write_prefilter_db(hits, queries, scores, test_map, train_map, clip=True):
-    """Returns (data bytes, index bytes) as the reference writes them (float64 arithmetic for the
-    clipped branch: numpy 1.22's value-based casting of the 10**30 bounds)."""
+def write_prefilter_db(hits, queries, scores, test_map, train_map, clip=True, numpy2=None):
+    """Returns (data bytes, index bytes) as the reference writes them.  Clipped branch: double
+    arithmetic under numpy 1.x (the reference pins 1.22.2: value-based casting of the 10**30
+    bounds), float32 under numpy >= 2 (NEP 50); numpy2=None follows the running numpy."""
     data, index = bytearray(), bytearray()
     offset = 0
-    if clip:
+    if numpy2 is None:
+        numpy2 = int(np.__version__.split(".")[0]) >= 2
+    if clip and numpy2:
+        scores_int = np.clip(scores.astype(np.float32), np.float32(-1e30), np.float32(1e30)) * np.float32(100)
+    elif clip:
         scores_int = np.clip(scores.astype(np.float64), -(10 ** 30), 10 ** 30) * 100
     else:
         scores_int = scores * np.float32(100)

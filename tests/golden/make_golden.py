@@ -21,6 +21,17 @@ What it does
    k in {5, 10, 11, 13, 100, min(1000, nb)}, plus fp64 ground-truth ids, as
    ``oracle_<dataset>.npz``.
 
+4. Imports the reference's own consumers of (hits, scores) -- ``write_prefilter_db``
+   (``seqvec_search/mmseqs/_write_prefilter_db.py:52-97``), ``compute_tps_comulative``
+   (``seqvec_search/tp_cumulative.py:15-34``) and ``evaluate_faiss`` / ``evaluate``
+   (``seqvec_search/main.py:53-82``) -- runs them on the pfam-20-10 / small-random results and
+   on a synthetic case (missing hits, huge / negative / rounding-edge scores, clip on and
+   off) and saves the bytes and arrays THEY produced as ``reference_consumers.npz``.
+   The reference ran under this container's numpy (version stored in the file): with
+   numpy >= 2 ``numpy.clip(float32, -(10**30), 10**30) * 100`` stays float32, with the
+   reference's pinned numpy 1.22.2 (``poetry.lock:222-223``) it is evaluated in double;
+   the product follows whichever numpy its caller runs.
+
 Nothing from the reference's *source* is copied; only data files.
 """
 import json
@@ -93,6 +104,91 @@ def reference_driven():
     print("reference-driven known answers reproduced")
 
 
+def _import_reference():
+    fake = types.ModuleType("faiss")
+    for n in dir(ko.OracleFaiss):
+        if not n.startswith("__"):
+            setattr(fake, n, getattr(ko.OracleFaiss, n))
+    sys.modules["faiss"] = fake
+    import matplotlib
+    matplotlib.use("Agg")
+    matplotlib.rcParams.validate["svg.hashsalt"] = lambda v: None if v is None else str(v)
+    if str(REF) not in sys.path:
+        sys.path.insert(0, str(REF))
+
+
+def reference_consumers():
+    """Bytes / arrays written by the reference's own write_prefilter_db, evaluate_faiss and
+    compute_tps_comulative (see the module docstring, item 4)."""
+    import tempfile
+    _import_reference()
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        from seqvec_search.mmseqs import write_prefilter_db
+        from seqvec_search.tp_cumulative import compute_tps_comulative
+        import seqvec_search.main as ref_main
+        from seqvec_search.data import LoadedData
+        driven = np.load(HERE / "reference_driven.npz")
+        out = {"numpy_version": np.asarray(np.__version__)}
+
+        def run_writer(tag, hits, queries, scores, test_map, train_map, clip):
+            with tempfile.TemporaryDirectory() as td:
+                db = Path(td) / "prefilter"
+                write_prefilter_db(hits, db, queries, scores, test_map, train_map, clip=clip)
+                for suffix, name in ((".0", "data"), (".index", "index"), (".dbtype", "dbtype")):
+                    out[f"{tag}_{name}"] = np.frombuffer(db.with_suffix(suffix).read_bytes(), np.uint8)
+
+        # A. the pfam-20-10 cosine k=10 result of the reference-driven run
+        rng = np.random.default_rng(101)
+        hits, scores = driven["pfam_20_10_ids"], driven["pfam_20_10_scores"]
+        queries = np.arange(hits.shape[0])
+        test_map = rng.permutation(5000)[: hits.shape[0]].astype(np.int64)
+        train_map = rng.permutation(5000)[:200].astype(np.int64)
+        out["pfam_test_map"], out["pfam_train_map"] = test_map, train_map
+        for clip in (True, False):
+            run_writer(f"pfam_clip{int(clip)}", hits, queries, scores, test_map, train_map, clip)
+        # B. synthetic: missing hits, huge / negative / rounding-edge scores, shuffled queries
+        nq, k, nb = 40, 12, 60
+        hits = np.stack([rng.permutation(nb)[:k] for _ in range(nq)]).astype(np.int64)
+        hits[rng.random((nq, k)) < 0.1] = -1
+        hits[3] = -1
+        scores = rng.standard_normal((nq, k)).astype(np.float32) * 3
+        edge = np.asarray([0.29, 0.57, 1.15, -0.29, 123.456, -1e-9, 0.999999, 8.2, 16.1, -33.33, 1e35, -1e35], np.float32)
+        scores[0] = edge
+        scores[1] = -edge
+        hits[0] = np.arange(k)
+        hits[1] = np.arange(k) + 7
+        queries = rng.permutation(nq).astype(np.int64)
+        test_map = rng.permutation(900)[:nq].astype(np.int64)
+        train_map = (rng.permutation(900)[:nb] + 1000).astype(np.int64)
+        out["syn_hits"], out["syn_queries"], out["syn_test_map"], out["syn_train_map"] = hits, queries, test_map, train_map
+        out["syn_scores_clip1"] = scores.copy()
+        run_writer("syn_clip1", hits, queries, scores, test_map, train_map, True)
+        scores2 = scores.copy()
+        scores2[np.abs(scores2) > 1e30] = 7.0  # clip=False would overflow int(inf) in the reference
+        out["syn_scores_clip0"] = scores2
+        run_writer("syn_clip0", hits, queries, scores2, test_map, train_map, False)
+        # C. evaluation: AUC1 / TP lists and the cumulative TP curve
+        for ds, k in (("small-random", 5), ("pfam-20-10", 10)):
+            key = ds.replace("-", "_")
+            data = LoadedData.from_options(path=Path("test-data") / ds, hits=k)
+            results = driven[f"{key}_ids"]
+            auc1s, tps = ref_main.evaluate_faiss(data, results)
+            assert np.array_equal(auc1s, driven[f"{key}_auc1s"]) and np.array_equal(tps, driven[f"{key}_tps"])
+            out[f"{key}_tp_cumulative"] = compute_tps_comulative(data, results)
+            # and for an arbitrary (not nearest-neighbour) result table
+            rnd = np.stack([rng.permutation(len(data.train_ids))[: 2 * k] for _ in range(len(data.test_ids))]).astype(np.int64)
+            a2, t2 = ref_main.evaluate_faiss(data, rnd)
+            out[f"{key}_random_results"] = rnd
+            out[f"{key}_random_auc1s"], out[f"{key}_random_tps"] = np.asarray(a2), np.asarray(t2)
+            out[f"{key}_random_tp_cumulative"] = compute_tps_comulative(data, rnd)
+        np.savez_compressed(HERE / "reference_consumers.npz", **out)
+    finally:
+        os.chdir(cwd)
+    print("reference consumers: prefilter bytes + evaluation arrays written")
+
+
 def oracle_vectors():
     orc = ko.oracle()
     for ds in DATASETS:
@@ -125,4 +221,5 @@ def oracle_vectors():
 if __name__ == "__main__":
     copy_fixtures()
     reference_driven()
+    reference_consumers()
     oracle_vectors()

@@ -34,10 +34,54 @@ def test_prefilter_db_bytes(tmp_path):
             scores[1, 0] = scores[2, 0] = 1.0
         db = tmp_path / f"prefilter_{clip}"
         write_prefilter_db(hits, db, queries, scores, test_map, train_map, clip=clip)
-        want_data, want_index = co.write_prefilter_db(hits, queries, scores, test_map, train_map, clip=clip)
+        want_data, want_index = co.write_prefilter_db(hits, queries, scores, test_map, train_map, clip=clip)  # follows the running numpy, as the wrapper does
         assert db.with_suffix(".dbtype").read_bytes() == b"\x07\x00\x00\x00"
         assert db.with_suffix(".0").read_bytes() == want_data
         assert db.with_suffix(".index").read_bytes() == want_index
+
+
+def test_prefilter_db_against_reference_written_bytes(tmp_path):
+    """tests/golden/reference_consumers.npz holds the bytes the REFERENCE's own write_prefilter_db
+    (seqvec_search/mmseqs/_write_prefilter_db.py:52-97) wrote in the build container (make_golden.py): the
+    pfam-20-10 k=10 result and a synthetic table with missing hits, huge / negative / rounding-edge scores,
+    clip on and off.  The reference ran under numpy 2.x there, where clip=True stays float32 (mode 2)."""
+    from knn_for_homology_amd import _lib
+    from knn_for_homology_amd.seqvec_search.mmseqs import write_prefilter_db
+    from oracle import consumers_oracle as co
+    g = np.load(GOLDEN / "reference_consumers.npz")
+    assert int(str(g["numpy_version"]).split(".")[0]) >= 2
+    d = np.load(GOLDEN / "reference_driven.npz")
+    cases = [("pfam", d["pfam_20_10_ids"], np.arange(200), {1: d["pfam_20_10_scores"], 0: d["pfam_20_10_scores"]},
+              g["pfam_test_map"], g["pfam_train_map"]),
+             ("syn", g["syn_hits"], g["syn_queries"], {1: g["syn_scores_clip1"], 0: g["syn_scores_clip0"]},
+              g["syn_test_map"], g["syn_train_map"])]
+    L = _lib.lib()
+    for tag, hits, queries, scores, tmap, rmap in cases:
+        for clip in (1, 0):
+            want_data, want_index = bytes(g[f"{tag}_clip{clip}_data"]), bytes(g[f"{tag}_clip{clip}_index"])
+            assert bytes(g[f"{tag}_clip{clip}_dbtype"]) == b"\x07\x00\x00\x00"
+            # the C entry point, float32 flavour of clip=True (what numpy >= 2 makes of the reference's line 75)
+            h = np.ascontiguousarray(hits, np.int64)
+            s = np.ascontiguousarray(scores[clip], np.float32)
+            q = np.ascontiguousarray(queries, np.int64)
+            data_f, index_f = tmp_path / f"{tag}{clip}.0", tmp_path / f"{tag}{clip}.index"
+            _lib.check(L.knn_write_prefilter_db(str(data_f).encode(), str(index_f).encode(), h.ctypes.data, s.ctypes.data, h.shape[0],
+                                                h.shape[1], q.ctypes.data, tmap.ctypes.data, tmap.shape[0], rmap.ctypes.data,
+                                                rmap.shape[0], 2 if clip else 0))
+            assert data_f.read_bytes() == want_data and index_f.read_bytes() == want_index
+            # the oracle restatement agrees with the reference's bytes too
+            od, oi = co.write_prefilter_db(hits, queries, scores[clip], tmap, rmap, clip=bool(clip), numpy2=True)
+            assert od == want_data and oi == want_index
+            # and so does the drop-in wrapper when the caller runs numpy >= 2 (as this container does)
+            if int(np.__version__.split(".")[0]) >= 2:
+                db = tmp_path / f"w_{tag}{clip}"
+                write_prefilter_db(hits, db, queries, scores[clip], tmap, rmap, clip=bool(clip))
+                assert db.with_suffix(".0").read_bytes() == want_data and db.with_suffix(".index").read_bytes() == want_index
+    # numpy 1.x semantics (the reference's pinned 1.22.2) differ exactly where float32 rounds up across an integer
+    syn1 = bytes(g["syn_clip1_data"])
+    od1, _ = co.write_prefilter_db(g["syn_hits"], g["syn_queries"], g["syn_scores_clip1"], g["syn_test_map"], g["syn_train_map"],
+                                   clip=True, numpy2=False)
+    assert od1 != syn1 and b"\t28\t0" in od1 and b"\t29\t0" in syn1
 
 
 def test_prefilter_db_empty_rows(tmp_path):
@@ -88,6 +132,28 @@ def test_evaluate_and_tp_cumulative_on_fixture(gpu_faiss):
     assert auc1s == a3 and tps == t3
     cum = evaluation.compute_tps_comulative(data, results)
     assert np.array_equal(cum, co.compute_tps_comulative(data.ids_to_family, data.train_ids, data.test_ids, results))
+
+
+@pytest.mark.gpu
+def test_evaluation_against_reference_written_arrays(gpu_faiss):
+    """AUC1 / TP lists and cumulative-TP curves computed by the REFERENCE's evaluate_faiss and compute_tps_comulative
+    (tests/golden/make_golden.py -> reference_consumers.npz), on its nearest-neighbour results and on arbitrary tables."""
+    from knn_for_homology_amd import evaluation
+    from knn_for_homology_amd.seqvec_search.data import LoadedData
+    from knn_for_homology_amd.seqvec_search.main import evaluate_faiss
+    g = np.load(GOLDEN / "reference_consumers.npz")
+    d = np.load(GOLDEN / "reference_driven.npz")
+    for ds, k in (("small-random", 5), ("pfam-20-10", 10)):
+        key = ds.replace("-", "_")
+        data = LoadedData.from_options(GOLDEN / ds, hits=k)
+        for results, auc_w, tp_w, cum_w in ((d[f"{key}_ids"], d[f"{key}_auc1s"], d[f"{key}_tps"], g[f"{key}_tp_cumulative"]),
+                                            (g[f"{key}_random_results"], g[f"{key}_random_auc1s"], g[f"{key}_random_tps"],
+                                             g[f"{key}_random_tp_cumulative"])):
+            auc1s, tps = evaluation.evaluate_faiss(data, results)
+            assert np.array_equal(np.asarray(auc1s), auc_w) and np.array_equal(np.asarray(tps), tp_w)
+            a2, t2 = evaluate_faiss(data, results)  # the host-side mirror in seqvec_search/main.py
+            assert np.array_equal(np.asarray(a2), auc_w) and np.array_equal(np.asarray(t2), tp_w)
+            assert np.array_equal(evaluation.compute_tps_comulative(data, results), cum_w)
 
 
 @pytest.mark.gpu
