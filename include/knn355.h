@@ -231,7 +231,14 @@ float knn_last_scan_ms(knn_handle h);
  * most max_n), each from a hipEvent pair recorded around the launch on the stream it
  * was launched on; -1 for a launch that has not finished.  Returns the count. */
 int32_t knn_scan_times(knn_handle h, float *out_ms, int32_t max_n);
-/* force a scan configuration: query_tile in {0(auto),32,64,128}; nchunks 0=auto */
+/* how the last search on this handle was seeded: seed_stride = 0 (no seed sample) or the
+ * stride of the sample searched first; stat_rank = 0 (the sample's k-th score, a proven bound)
+ * or j (statistical seed: the sample's j-th score, result verified); stat_redo = searches
+ * repeated so far because a statistical threshold failed its verification */
+int knn_last_seed_info(knn_handle h, int32_t *seed_stride, int32_t *stat_rank, int64_t *stat_redo);
+/* force a scan configuration: query_tile in {0(auto),32,64,128}; nchunks 0=auto;
+ * flags: 8 = no seed sample, 16 = force the exact seed, 128 = force the statistical seed
+ * (synchronous entry points only), 512 = never use the statistical seed */
 int knn_set_tuning(knn_handle h, int32_t query_tile, int32_t nchunks, int32_t flags);
 
 #ifdef __cplusplus

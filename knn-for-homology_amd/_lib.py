@@ -83,6 +83,7 @@ def _declare(L):
         "knn_eval_levels": (c_int32, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
         "knn_write_prefilter_db": (c_int32, [c_char_p, c_char_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32]),
         "knn_scan_times": (c_int32, [H, c_void_p, c_int32]),
+        "knn_last_seed_info": (c_int32, [H, POINTER(c_int32), POINTER(c_int32), POINTER(c_int64)]),
         "knn_flat_reserve": (c_int32, [H, c_int64]),
     }
     for name, (res, args) in sig.items():

@@ -447,28 +447,31 @@ struct ScanParams {
     int64_t chunk_rows; // multiple of the database tile
     uint64_t *lists;   // [grid][QT][cap]
     uint32_t *gthr;    // [nqtiles*QT] shared running thresholds (order-mapped floats)
-    uint64_t *partial; // [nq][nchunks][k]
+    uint64_t *qlist;   // [nq][qcap] compact candidate arrays: the chunks' survivors, appended as they finish
+    uint32_t *qcnt;    // [nq] fill of each array
+    int qcap;
     uint32_t id_base;
     int row_mul;       // this launch scans a block-strided view of the database, see view_row()
-    int skip_mask;     // >= 0: rows whose 8-row block b has (b & skip_mask) == 0 belong to the seed sample, skip them
-    int kslot;         // keys per (query, list) slot in `partial`: k + k/4
-    int partial_lists; // lists per query in `partial` (nchunks, +1 when a seed list rides along)
+    int vshift;        // log2 of the view's block size (3: blocks of 8 rows, 0: single rows)
+    int skip_mask;     // >= 0: rows whose block b has (b & skip_mask) == 0 belong to the seed sample, skip them
+    int kslot;         // most keys a chunk hands on per query: k + k/4
 };
 
-// Views: view row r of a launch with stride row_mul is database row
-// (r / 8) * 8 * row_mul + r % 8 -- blocks of 8 consecutive rows, every row_mul-th block
-// (row_mul = 1: the database itself).  Blocks rather than single rows because one staging
-// instruction fetches 8 rows: 8 rows 32 KB apart in one page instead of 8 pages (a row-strided
-// sample of a 41 GB database ran at 1.9 TB/s, bound by address translation).
-#define KNN_VIEW_BLOCK_SHIFT 3
-__host__ __device__ __forceinline__ int64_t view_row(int64_t r, int row_mul)
+// Views: view row r of a launch with stride row_mul and block size B = 1 << vshift is database row
+// (r / B) * B * row_mul + r % B -- blocks of B consecutive rows, every row_mul-th block (row_mul = 1:
+// the database itself).  Seed samples of the streaming regime use blocks of 8 rows, because one
+// staging instruction fetches 8 rows: 8 rows 32 KB apart in one page instead of 8 pages (a
+// row-strided sample of a 41 GB database ran at 1.9 TB/s, bound by address translation); the
+// statistical samples of the batch regime use single rows (a stratified sample of a database
+// whose families sit next to each other).
+__host__ __device__ __forceinline__ int64_t view_row(int64_t r, int row_mul, int vshift)
 {
-    return ((r >> KNN_VIEW_BLOCK_SHIFT) * row_mul << KNN_VIEW_BLOCK_SHIFT) + (r & ((1 << KNN_VIEW_BLOCK_SHIFT) - 1));
+    return ((r >> vshift) * row_mul << vshift) + (r & (((int64_t)1 << vshift) - 1));
 }
 // rows of the view with stride row_mul over a database of n rows
-static inline int64_t view_rows(int64_t n, int row_mul)
+static inline int64_t view_rows(int64_t n, int row_mul, int vshift)
 {
-    const int64_t B = 1 << KNN_VIEW_BLOCK_SHIFT, span = B * row_mul;
+    const int64_t B = (int64_t)1 << vshift, span = B * row_mul;
     if (n <= 0) return 0;
     const int64_t last = (n - 1) / span; // last block that starts inside the database
     return last * B + std::min<int64_t>(B, n - last * span);
@@ -508,13 +511,12 @@ struct ListCtx {
     }
 };
 
-// Called by all threads after a tile's appends (and a barrier).  Lists that could overflow on
-// the next tile are cut back to [k, 1.25k] keys; on the last tile every list is cut to at most
-// kslot = 1.25k keys (no work at all if it already is that short) and written, unsorted and
-// padded, to out_base + ql * out_stride.  Exactness is the merge kernel's job.
+// Called by all threads after a tile's appends (and a barrier).  Lists that could overflow on the
+// next tile are cut back to the best [k, min(1.25k, cap - tile)] keys; with `final` set (end of the
+// chunk) every list longer than kslot is cut to at most kslot keys instead.  Cuts happen in place
+// (survivors packed to the front of the list, unsorted); exactness is the final selection's job.
 template <int QT, int NT = 256>
-__device__ __forceinline__ void lists_compact(ListCtx &L, char *smem, int tile_rows, bool last_tile, int64_t nq_valid,
-                                              uint64_t *out_base, size_t out_stride, int tid)
+__device__ __forceinline__ void lists_compact(ListCtx &L, char *smem, int tile_rows, bool final, int tid)
 {
     const int lane = tid & 63, wave = tid >> 6;
     const int R = L.cap >> 6;
@@ -524,26 +526,24 @@ __device__ __forceinline__ void lists_compact(ListCtx &L, char *smem, int tile_r
             const int n = __builtin_amdgcn_readfirstlane(min(L.s_cnt[ql], L.cap));
             uint64_t *lst = L.lists + (size_t)ql * L.cap;
             uint32_t T = 0;
-            if (!last_tile) {
+            int kmax;
+            if (!final) {
                 if (n <= L.cap - tile_rows) continue;
                 // at most cap - tile_rows keys may stay: the next tile can append tile_rows more
                 // (k in (1433, 1536] with 256-row tiles: 1.25 k alone would leave too little room)
-                const int cnt = wave_select_dispatch(R, LoadContig{lst}, n, L.k, min(L.k + (L.k >> 2), L.cap - tile_rows), lane, &T, lst);
-                if (lane == 0) {
-                    L.s_cnt[ql] = cnt;
-                    L.s_thr[ql] = ord2f(T);
-                    atomicMin(&L.gthr[ql], T);
-                }
+                kmax = min(L.k + (L.k >> 2), L.cap - tile_rows);
             } else {
-                if (ql >= nq_valid) continue;
-                uint64_t *out = out_base + (size_t)ql * out_stride;
-                if (n > L.kslot) {
-                    const int cnt = wave_select_dispatch(R, LoadContig{lst}, n, L.k, L.kslot, lane, &T, out);
-                    for (int i = cnt + lane; i < L.kslot; i += 64) out[i] = KEY_PAD;
-                    if (lane == 0) atomicMin(&L.gthr[ql], T);
-                } else {
-                    for (int i = lane; i < L.kslot; i += 64) out[i] = i < n ? lst[i] : KEY_PAD;
+                if (n <= L.kslot) {
+                    if (lane == 0) L.s_cnt[ql] = n;
+                    continue;
                 }
+                kmax = L.kslot;
+            }
+            const int cnt = wave_select_dispatch(R, LoadContig{lst}, n, L.k, kmax, lane, &T, lst);
+            if (lane == 0) {
+                L.s_cnt[ql] = cnt;
+                L.s_thr[ql] = ord2f(T);
+                atomicMin(&L.gthr[ql], T);
             }
         }
         __syncthreads();
@@ -552,19 +552,18 @@ __device__ __forceinline__ void lists_compact(ListCtx &L, char *smem, int tile_r
         uint64_t *sb = (uint64_t *)smem;
         for (int ql = 0; ql < QT; ql++) {
             const int n = min(L.s_cnt[ql], L.cap);
-            if (!last_tile && n <= L.cap - tile_rows) continue;
+            if (!final && n <= L.cap - tile_rows) continue;
+            if (final && n <= L.kslot) {
+                if (tid == 0) L.s_cnt[ql] = n; // (readers clamp with cap themselves: old or new value, same n)
+                continue;
+            }
             uint64_t *lst = L.lists + (size_t)ql * L.cap;
             const int P = next_pow2_dev(n > 0 ? n : 1);
             for (int i = tid; i < P; i += NT) sb[i] = i < n ? lst[i] : KEY_PAD;
             __syncthreads();
             wg_bitonic_sort(sb, P, tid, NT);
             const int keep = min(n, L.k);
-            if (!last_tile) {
-                for (int i = tid; i < keep; i += NT) lst[i] = sb[i];
-            } else if (ql < nq_valid) {
-                uint64_t *out = out_base + (size_t)ql * out_stride;
-                for (int i = tid; i < L.kslot; i += NT) out[i] = i < keep ? sb[i] : KEY_PAD;
-            }
+            for (int i = tid; i < keep; i += NT) lst[i] = sb[i];
             if (tid == 0) {
                 L.s_cnt[ql] = keep;
                 if (n >= L.k) {
@@ -578,6 +577,30 @@ __device__ __forceinline__ void lists_compact(ListCtx &L, char *smem, int tile_r
     }
     if (tid == 0) *L.s_need = 0;
     __syncthreads();
+}
+
+// End of a chunk (after lists_compact(final)): every query's survivors are appended to its compact
+// candidate array qlist[q][0 .. qcap) behind whatever other chunks (and the seed sample) have put
+// there: one atomic add per (workgroup, query) reserves the slots, then the keys are copied, one
+// wave per query.  qcap = (lists per query) x kslot: the reservations can never run past it.
+template <int QT, int NT = 256>
+__device__ __forceinline__ void lists_flush(ListCtx &L, int *s_base, int64_t q0, int64_t nq, uint64_t *qlist, uint32_t *qcnt,
+                                            int qcap, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    const int nqv = (int)min((int64_t)QT, nq - q0);
+    for (int ql = tid; ql < nqv; ql += NT) {
+        const int n = L.s_cnt[ql];
+        s_base[ql] = n > 0 ? (int)atomicAdd(&qcnt[q0 + ql], (uint32_t)n) : 0;
+    }
+    __syncthreads();
+    for (int ql = wave; ql < nqv; ql += NT / 64) {
+        const int n = L.s_cnt[ql], base = s_base[ql];
+        const uint64_t *lst = L.lists + (size_t)ql * L.cap;
+        uint64_t *dst = qlist + (size_t)(q0 + ql) * qcap + base;
+        for (int i = lane; i < n; i += 64)
+            if (base + i < qcap) dst[i] = lst[i];
+    }
 }
 
 // one staging instruction: 64 lanes x 16 B straight from global memory into LDS (LDS-DMA, no VGPR
@@ -601,13 +624,11 @@ __device__ __forceinline__ void sched_spread()
 }
 
 // WM x WN waves; each wave owns TM x TN MFMA tiles of 32(db rows) x 32(queries)
-// SAMPLE only names the instantiation that scans a seed sample, so that profiles keep the
-// (tiny) sample launches apart from the main pass of the same configuration.
 // NTDB: the launch has ONE query tile, so every database row is read by exactly one workgroup:
 // its staging loads are non-temporal and do not displace the queries (re-read by every workgroup
 // each K step) from L2 / Infinity Cache -- 10 M x 32 queries +4 %.  With several query tiles the
 // workgroups of a chunk share the rows through L2 and non-temporal loads cost 3 %.
-template <int WM, int WN, int TM, int TN, bool L2, bool SAMPLE = false, bool NTDB = false>
+template <int WM, int WN, int TM, int TN, bool L2, bool NTDB = false>
 __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 {
     static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -638,7 +659,8 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
     L.s_thr = (float *)(smem + lds_main);
     L.s_cnt = (int *)(L.s_thr + QT);
     L.s_need = L.s_cnt + QT;
-    float *s_yn = (float *)(L.s_need + 4); // [DT] squared norms of the current tile's rows (L2 only)
+    int *s_base = L.s_need + 4;            // [QT] first slot of each query's survivors in its compact array
+    float *s_yn = (float *)(s_base + QT);  // [DT] squared norms of the current tile's rows (L2 only)
     L.lists = p.lists + (size_t)blockIdx.x * QT * p.cap;
     L.gthr = p.gthr + (size_t)qtile * QT;
     L.cap = p.cap;
@@ -686,7 +708,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 #pragma unroll
         for (int n = 0; n < NI; n++) {
             if (is_db[n]) {
-                int64_t r = view_row(min(row0 + rloc[n], p.nb - 1), p.row_mul);
+                int64_t r = view_row(min(row0 + rloc[n], p.nb - 1), p.row_mul, p.vshift);
                 tsrc[n] = srcp[n] + r * p.dp;
             } else {
                 tsrc[n] = srcp[n];
@@ -696,7 +718,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
             // the tile's squared norms: one coalesced load per thread now, LDS reads in the epilogue
             // (visible after the K loop's barriers) instead of 16 * TM * TN scattered global loads
             // per lane at the end of the tile
-            if (tid < DT) s_yn[tid] = p.yn[view_row(min(row0 + tid, p.nb - 1), p.row_mul)];
+            if (tid < DT) s_yn[tid] = p.yn[view_row(min(row0 + tid, p.nb - 1), p.row_mul, p.vshift)];
         }
         // One K step of MFMA work from buffer `cur`.  `dma(n)` (n < NI) issues this wave's n-th
         // staging instruction of the NEXT K step; the NI of them are spread between the MFMAs so
@@ -798,8 +820,8 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
                     } else {
                         v = -acc[a][b][r];
                     }
-                    if (v <= thr && row < c_hi && qok && !(p.skip_mask >= 0 && ((int)(row >> KNN_VIEW_BLOCK_SHIFT) & p.skip_mask) == 0))
-                        L.append(ql, v, p.id_base + (uint32_t)view_row(row, p.row_mul), DT);
+                    if (v <= thr && row < c_hi && qok && !(p.skip_mask >= 0 && ((int)(row >> p.vshift) & p.skip_mask) == 0))
+                        L.append(ql, v, p.id_base + (uint32_t)view_row(row, p.row_mul, p.vshift), DT);
                 }
             }
         }
@@ -807,189 +829,239 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 
         // ---- compaction of lists that could overflow on the next tile ----
         const bool last_tile = row0 + DT >= c_hi;
-        if (*L.s_need || last_tile)
-            lists_compact<QT>(L, smem, DT, last_tile, p.nq - q0, p.partial + ((size_t)q0 * p.partial_lists + chunk) * p.kslot,
-                              (size_t)p.partial_lists * p.kslot, tid);
+        if (*L.s_need || last_tile) lists_compact<QT>(L, smem, DT, last_tile, tid);
     }
+    lists_flush<QT>(L, s_base, q0, p.nq, p.qlist, p.qcnt, p.qcap, tid);
 }
 
-// gthr[q] <- score word of the k-th seed key (padding reads as "no bound")
-__global__ void seed_thresholds_kernel(const uint64_t *__restrict__ seed_keys, int64_t key_stride, int k, int64_t nq,
-                                       int64_t nslots, uint32_t *__restrict__ gthr)
+// ---------------------------------------------------------------------------
+// final selection: one workgroup per query picks the best k of that query's candidate keys,
+// sorts them and emits D / I, sorted keys, or the seed of the enclosing search.
+//   input   contiguous: keys in + q * in_stride, count cnt[q] (clamped to cap) or n_fixed
+//           list-major: an all-gather buffer [lm_lists][nq][lm_k] (KEY_PAD = no key)
+//   method  keys are distinct 64-bit numbers (score word << 32 | row id), so f(X) = #(keys < X)
+//           takes every value: a bracket search on X -- probes alternate between linear
+//           interpolation of the target rank and bisection -- stops at the first X with
+//           k <= f(X) <= kmax (3-6 probes; heavy ties on the score word are spread by the id
+//           word).  Up to 256 * R keys live in registers (one compare + add per key and probe);
+//           longer arrays are re-read from L2 on every probe.  The <= kmax survivors are packed
+//           into LDS and sorted by the whole workgroup.
+// ---------------------------------------------------------------------------
+struct SelectParams {
+    const uint64_t *in;
+    int64_t in_stride;
+    const uint32_t *cnt;
+    int n_fixed, cap;
+    int lm_lists, lm_k;
+    int64_t nq;
+    int k, metric;
+    uint64_t *out_keys;   // sorted keys (may be null): k per query at out_keys + q * out_stride, padded with KEY_PAD up to out_fill
+    int64_t out_stride;
+    int out_fill;
+    float *D;             // final distances / ids (may be null)
+    int64_t *I;
+    // seeding the enclosing search from this (sample) result: its candidate count, its running
+    // threshold = the score word of the seed_j-th key (no bound if there are fewer), and -- for a
+    // statistical seed -- the same word as the bound its own result is verified against
+    uint32_t *seed_cnt, *seed_gthr, *seed_qthr;
+    int seed_j, seed_stat;
+    const uint32_t *qthr; // verification: a k-th score word above qthr[q] means the statistical threshold was too tight
+    int *fail;
+};
+
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t x)
 {
-    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nslots) return;
-    gthr[q] = q < nq ? (uint32_t)(seed_keys[q * key_stride + (k - 1)] >> 32) : 0xFFFFFFFFu;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t y = __shfl_xor(x, o, 64);
+        x = y < x ? y : x;
+    }
+    return x;
+}
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t x)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t y = __shfl_xor(x, o, 64);
+        x = y > x ? y : x;
+    }
+    return x;
 }
 
-// ---------------------------------------------------------------------------
-// merge: one WAVE per (query, group of <= G lists).  in is [nq][L][k] or, for an
-// all-gather buffer, [L][nq][k]; lists are unsorted and padded with KEY_PAD.
-// The wave pulls the group's <= 4096 keys into registers, keeps the best k
-// (wave_select, exact) and either writes them on as an unsorted list
-// (out_keys [nq][Lout][k], more rounds follow) or -- last round, Lout == 1 --
-// sorts them in LDS and emits the final D / I (or sorted keys).
-// ---------------------------------------------------------------------------
-// RMAX: most keys per lane any wave of this launch holds (16, 32 or 64): the register count of the
-// instantiation, hence how many waves share a SIMD -- merges of many queries are latency-bound and
-// live on that.
-template <bool LISTMAJOR, int RMAX>
-__global__ __launch_bounds__(256) void merge_select_kernel(const uint64_t *__restrict__ in, int L, int kin, int k,
-                                                           int64_t nq, int G, int Lout, uint64_t *__restrict__ out_keys,
-                                                           int64_t out_key_stride, int out_key_fill, int final_round,
-                                                           int metric, float *__restrict__ D, int64_t *__restrict__ I)
+template <int R>
+__global__ __launch_bounds__(256) void select_topk_kernel(SelectParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t *sb = (uint64_t *)smem; // [P] survivors, sorted in place
+    __shared__ int s_red[2][4];
+    __shared__ int s_scan[4];
+    __shared__ uint64_t s_mm[2][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int P = 64;
-    while (P < k) P <<= 1;
-    uint64_t *sb = (uint64_t *)smem + (size_t)wave * P; // final round only
-    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
-    const int64_t nitems = nq * Lout;
-    const bool active = item < nitems;
-    const int64_t q = active ? item / Lout : 0;
-    const int g = active ? (int)(item % Lout) : 0;
-    const int l0 = g * G, l1 = min(L, l0 + G);
-    const int n = (l1 - l0) * kin; // input lists hold kin keys each (kin >= k), output lists k
-    uint64_t *dst = final_round ? sb : out_keys + ((size_t)q * Lout + g) * k;
-    if (active) {
-        int have = n;
-        if (n > k) {
-            uint32_t T;
-            const int R = (n + 63) >> 6;
-            if constexpr (LISTMAJOR)
-                have = wave_select_dispatch_max<RMAX>(R, LoadListMajor{in, nq, q, kin, l0}, n, k, k, lane, &T, dst);
-            else
-                have = wave_select_dispatch_max<RMAX>(R, LoadContig{in + ((size_t)q * L + l0) * kin}, n, k, k, lane, &T, dst);
-        } else {
-            for (int i = lane; i < n; i += 64) {
-                if constexpr (LISTMAJOR) dst[i] = LoadListMajor{in, nq, q, kin, l0}(i);
-                else dst[i] = in[((size_t)q * L + l0) * kin + i];
-            }
+    const int64_t q = blockIdx.x;
+    const int k = p.k;
+    int n = p.lm_lists > 0 ? p.lm_lists * p.lm_k : (p.cnt ? (int)min(p.cnt[q], (uint32_t)p.cap) : p.n_fixed);
+    auto load = [&](int idx) -> uint64_t {
+        if (p.lm_lists > 0) {
+            const int l = idx / p.lm_k, j = idx - l * p.lm_k;
+            return ((gptr_u64)p.in)[((size_t)l * p.nq + q) * p.lm_k + j];
         }
-        const int fill_to = final_round ? P : k;
-        for (int i = have + lane; i < fill_to; i += 64) dst[i] = KEY_PAD;
-    }
-    if (!final_round || !active) return;
-    // This wave sorts its own P keys in LDS.  One wave's LDS operations complete in order, so a
-    // wave-scope fence between the stages is all the synchronisation there is (no workgroup
-    // barrier: the four waves are independent).  Four compare-exchanges per lane are in flight at
-    // a time: the loads of a group are issued together instead of one dependent round trip per pair.
-    // (The keys arrived through generic-pointer stores, which do not take the DS path: a
-    // workgroup-scope fence drains them before the first DS read.)
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    const int half = P >> 1;
-    // NP compare-exchanges per lane and pass, no per-pair guards (half is 32, or a multiple of 64 * NP)
-    auto sort_with = [&](auto np_tag) {
-        constexpr int NP = decltype(np_tag)::value;
-        for (int k2 = 2; k2 <= P; k2 <<= 1) {
-            for (int j = k2 >> 1; j > 0; j >>= 1) {
-                for (int base = 0; base < half; base += 64 * NP) {
-                    int a[NP];
-                    uint64_t x[NP], y[NP];
-#pragma unroll
-                    for (int u = 0; u < NP; u++) {
-                        const int i = min(base + u * 64 + lane, half - 1); // only P = 64 clamps (lanes 32..63 idle)
-                        a[u] = ((i & ~(j - 1)) << 1) | (i & (j - 1));
-                        x[u] = sb[a[u]];
-                        y[u] = sb[a[u] + j];
-                    }
-#pragma unroll
-                    for (int u = 0; u < NP; u++) {
-                        if (base + u * 64 + lane < half && (x[u] > y[u]) == ((a[u] & k2) == 0)) {
-                            sb[a[u]] = y[u];
-                            sb[a[u] + j] = x[u];
-                        }
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            }
-        }
+        return ((gptr_u64)p.in)[(size_t)q * p.in_stride + idx];
     };
-    if (half <= 64) sort_with(std::integral_constant<int, 1>{});
-    else if (half == 128) sort_with(std::integral_constant<int, 2>{});
-    else sort_with(std::integral_constant<int, 4>{});
-    if (out_keys)
-        for (int i = k + lane; i < out_key_fill; i += 64) out_keys[(size_t)q * out_key_stride + i] = KEY_PAD;
-    for (int i = lane; i < k; i += 64) {
-        const uint64_t key = sb[i];
-        const size_t o = (size_t)q * k + i;
-        if (out_keys) out_keys[(size_t)q * out_key_stride + i] = key;
-        if (D) {
-            if (key == KEY_PAD) {
-                D[o] = metric == KNN_METRIC_INNER_PRODUCT ? -FLT_MAX : FLT_MAX;
-                I[o] = -1;
-            } else {
-                const float v = ord2f((uint32_t)(key >> 32));
-                D[o] = metric == KNN_METRIC_INNER_PRODUCT ? -v : v;
-                I[o] = (int64_t)(uint32_t)key;
+    const bool in_regs = n <= 256 * R;
+    uint64_t key[R];
+    uint64_t mn = KEY_PAD, mx = 0;
+    int real = 0;
+    if (in_regs) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int idx = r * 256 + tid;
+            uint64_t v = load(idx < n ? idx : (n > 0 ? n - 1 : 0));
+            if (idx >= n) v = KEY_PAD;
+            key[r] = v;
+            if (v != KEY_PAD) {
+                mn = v < mn ? v : mn;
+                mx = v > mx ? v : mx;
+                real++;
+            }
+        }
+    } else {
+        for (int idx = tid; idx < n; idx += 256) {
+            const uint64_t v = load(idx);
+            if (v != KEY_PAD) {
+                mn = v < mn ? v : mn;
+                mx = v > mx ? v : mx;
+                real++;
             }
         }
     }
-}
-
-// k > 1536 (beyond the reference's k = 1000): one workgroup sorts the union of up to G lists
-// (<= 8192 keys) of one query in LDS.  Same interface as merge_select_kernel.
-template <bool LISTMAJOR>
-__global__ __launch_bounds__(256) void merge_sort_kernel(const uint64_t *__restrict__ in, int L, int kin, int k, int64_t nq,
-                                                         int G, int Lout, uint64_t *__restrict__ out_keys,
-                                                         int64_t out_key_stride, int out_key_fill, int final_round,
-                                                         int metric, float *__restrict__ D, int64_t *__restrict__ I)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint64_t *sb = (uint64_t *)smem;
-    const int tid = threadIdx.x;
-    const int64_t q = blockIdx.x / Lout;
-    const int g = blockIdx.x % Lout;
-    const int l0 = g * G, l1 = min(L, l0 + G);
-    const int n = (l1 - l0) * kin;
-    int P = 64;
-    while (P < n) P <<= 1;
-    for (int i = tid; i < P; i += 256) {
-        uint64_t v = KEY_PAD;
-        if (i < n) {
-            const int l = l0 + i / kin, j = i % kin;
-            v = LISTMAJOR ? in[((size_t)l * nq + q) * kin + j] : in[((size_t)q * L + l) * kin + j];
-        }
-        sb[i] = v;
+    mn = wave_min_u64(mn);
+    mx = wave_max_u64(mx);
+    real = wave_sum(real);
+    if (lane == 0) {
+        s_mm[0][wave] = mn;
+        s_mm[1][wave] = mx;
+        s_scan[wave] = real;
     }
     __syncthreads();
-    wg_bitonic_sort(sb, P, tid, 256);
-    if (!final_round) {
-        uint64_t *o = out_keys + ((size_t)q * Lout + g) * k;
-        for (int i = tid; i < k; i += 256) o[i] = i < n ? sb[i] : KEY_PAD;
-        return;
-    }
-    for (int i = tid; i < max(k, out_key_fill); i += 256) {
-        const uint64_t key = i < k && i < n ? sb[i] : KEY_PAD;
-        if (out_keys) out_keys[(size_t)q * out_key_stride + i] = key;
-        if (D && i < k) {
-            const size_t o = (size_t)q * k + i;
-            if (key == KEY_PAD) {
-                D[o] = metric == KNN_METRIC_INNER_PRODUCT ? -FLT_MAX : FLT_MAX;
-                I[o] = -1;
+    mn = min(min(s_mm[0][0], s_mm[0][1]), min(s_mm[0][2], s_mm[0][3]));
+    mx = max(max(s_mm[1][0], s_mm[1][1]), max(s_mm[1][2], s_mm[1][3]));
+    real = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
+    __syncthreads(); // s_scan is reused below
+
+    int par = 0;
+    auto count_lt = [&](uint64_t X) -> int {
+        int c = 0;
+        if (in_regs) {
+#pragma unroll
+            for (int r = 0; r < R; r++) c += key[r] < X ? 1 : 0;
+        } else {
+            for (int idx = tid; idx < n; idx += 256) c += load(idx) < X ? 1 : 0;
+        }
+        c = wave_sum(c);
+        if (lane == 0) s_red[par][wave] = c;
+        __syncthreads();
+        c = s_red[par][0] + s_red[par][1] + s_red[par][2] + s_red[par][3];
+        par ^= 1; // the next probe writes the other set: one barrier per probe is enough
+        return c;
+    };
+    const int kmax = k + max(k >> 2, 32);
+    int cnt = real;
+    uint64_t T = KEY_PAD; // survivors: keys < T (KEY_PAD: every real key)
+    if (real > kmax) {
+        uint64_t lo = mn, hi = mx + 1; // f(lo) = 0 < k, f(hi) = real > kmax
+        int f_lo = 0, f_hi = real;
+        const double target = 0.5 * (double)(k + kmax);
+        bool interpolate = true;
+        for (int it = 0; it < 160; it++) {
+            const uint64_t w = hi - lo;
+            if (w <= 1) { // cannot happen while the keys are distinct; keep the kmax best of the tie
+                T = hi;
+                cnt = f_hi;
+                break;
+            }
+            uint64_t X;
+            if (interpolate) X = lo + (uint64_t)((double)w * ((target - (double)f_lo) / (double)(f_hi - f_lo)));
+            else X = lo + (w >> 1);
+            X = max(lo + 1, min(X, hi - 1));
+            interpolate = !interpolate;
+            const int c = count_lt(X);
+            if (c < k) {
+                lo = X;
+                f_lo = c;
+            } else if (c > kmax) {
+                hi = X;
+                f_hi = c;
             } else {
-                const float v = ord2f((uint32_t)(key >> 32));
-                D[o] = metric == KNN_METRIC_INNER_PRODUCT ? -v : v;
-                I[o] = (int64_t)(uint32_t)key;
+                T = X;
+                cnt = c;
+                break;
             }
         }
     }
-}
-
-__global__ void finalize_kernel(const uint64_t *__restrict__ keys, int64_t total, int metric,
-                                float *__restrict__ D, int64_t *__restrict__ I)
-{
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    uint64_t key = keys[i];
-    if (key == KEY_PAD) {
-        D[i] = metric == KNN_METRIC_INNER_PRODUCT ? -FLT_MAX : FLT_MAX;
-        I[i] = -1;
+    // pack the survivors into LDS (positions from a workgroup-wide exclusive scan of the per-thread counts)
+    int P = 64;
+    while (P < cnt) P <<= 1;
+    const int Pcap = 1 << (32 - __builtin_clz(kmax - 1)); // what the host sized the LDS for: next_pow2(kmax)
+    if (P > Pcap) P = Pcap;
+    int mine = 0;
+    if (in_regs) {
+#pragma unroll
+        for (int r = 0; r < R; r++) mine += key[r] < T ? 1 : 0;
     } else {
-        float v = ord2f((uint32_t)(key >> 32));
-        D[i] = metric == KNN_METRIC_INNER_PRODUCT ? -v : v;
-        I[i] = (int64_t)(uint32_t)key;
+        for (int idx = tid; idx < n; idx += 256) mine += load(idx) < T ? 1 : 0;
+    }
+    const int incl = wave_inclusive_scan(mine);
+    if (lane == 63) s_scan[wave] = incl;
+    __syncthreads();
+    int pos = incl - mine;
+    for (int w2 = 0; w2 < wave; w2++) pos += s_scan[w2];
+    if (in_regs) {
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if (key[r] < T) {
+                if (pos < P) sb[pos] = key[r];
+                pos++;
+            }
+    } else {
+        for (int idx = tid; idx < n; idx += 256) {
+            const uint64_t v = load(idx);
+            if (v < T) {
+                if (pos < P) sb[pos] = v;
+                pos++;
+            }
+        }
+    }
+    for (int i = cnt + tid; i < P; i += 256) sb[i] = KEY_PAD;
+    __syncthreads();
+    wg_bitonic_sort(sb, P, tid, 256);
+    cnt = min(cnt, P);
+    const int have = min(cnt, k); // real keys among the first k
+    for (int i = tid; i < max(k, p.out_fill); i += 256) {
+        const uint64_t v = i < have ? sb[i] : KEY_PAD;
+        if (p.out_keys) p.out_keys[(size_t)q * p.out_stride + i] = v;
+        if (p.D && i < k) {
+            const size_t o = (size_t)q * k + i;
+            if (v == KEY_PAD) {
+                p.D[o] = p.metric == KNN_METRIC_INNER_PRODUCT ? -FLT_MAX : FLT_MAX;
+                p.I[o] = -1;
+            } else {
+                const float f = ord2f((uint32_t)(v >> 32));
+                p.D[o] = p.metric == KNN_METRIC_INNER_PRODUCT ? -f : f;
+                p.I[o] = (int64_t)(uint32_t)v;
+            }
+        }
+    }
+    if (tid == 0) {
+        if (p.seed_cnt) {
+            const uint32_t thr = cnt >= p.seed_j ? (uint32_t)(sb[p.seed_j - 1] >> 32) : 0xFFFFFFFFu;
+            p.seed_cnt[q] = (uint32_t)have;
+            p.seed_gthr[q] = thr;
+            p.seed_qthr[q] = p.seed_stat ? thr : 0xFFFFFFFFu;
+        }
+        if (p.qthr && p.fail) {
+            const uint32_t kth = cnt >= k ? (uint32_t)(sb[k - 1] >> 32) : 0xFFFFFFFFu;
+            if (kth > p.qthr[q]) *p.fail = 1;
+        }
     }
 }
 
@@ -1141,6 +1213,12 @@ struct DevBuf {
     }
 };
 
+// per seed-recursion level: compact candidate arrays [nq][qcap] + their fill, the shared running
+// thresholds and the verification bounds of a statistically seeded pass
+struct LevelBufs {
+    DevBuf qlist, qcnt, gthr, qthr;
+};
+
 struct knn_index_s {
     int d = 0, dp = 0, metric = 0, device = 0;
     int num_cus = 256;
@@ -1159,11 +1237,14 @@ struct knn_index_s {
     hipEvent_t ring0[RING] = {nullptr}, ring1[RING] = {nullptr};
     int64_t nlaunches = 0;
     std::mutex mu;
-    DevBuf ws_q, ws_qn, ws_lists, ws_gthr, ws_partial, ws_partial2, ws_keys, ws_D, ws_I, ws_tmp, ws_tmp2;
+    DevBuf ws_q, ws_qn, ws_lists, ws_D, ws_I, ws_tmp, ws_tmp2;
     DevBuf ws_D1, ws_I1, ws_tmp3; // second set for the pipelined host search
-    DevBuf ws_merge0, ws_merge1;  // knn_merge_keys_dev: intermediate rounds (per handle, i.e. per lane)
-    DevBuf ws_level[8]; // per seed-recursion level: [nq][lists][k] survivor keys
-    int last_seed_stride = 0;
+    DevBuf ws_flag;               // [0]: a statistically seeded search failed its verification
+    static const int MAX_LEVELS = 8;
+    LevelBufs ws_level[MAX_LEVELS]; // per seed-recursion level
+    int last_seed_stride = 0, last_seed_stat = 0;
+    int64_t stat_redo = 0;        // searches repeated because the statistical threshold was too tight
+    int *flag_host = nullptr;     // pinned: [slot] copy of ws_flag behind each batch of a host search
     // tuning + introspection
     int force_qt = 0, force_chunks = 0, flags = 0;
     std::string last_kernel;
@@ -1341,15 +1422,20 @@ extern "C" void knn_free(knn_handle h)
         if (h->stream) (void)hipStreamSynchronize(h->stream);
         if (!h->is_view && h->xb) (void)hipDeviceSynchronize(); // a view's stream may still be scanning these rows
         free_index_buffers(h);
-        DevBuf *bufs[] = {&h->ws_merge0, &h->ws_merge1, &h->ws_q, &h->ws_qn, &h->ws_lists, &h->ws_gthr, &h->ws_partial, &h->ws_partial2,
-                          &h->ws_keys, &h->ws_D, &h->ws_I, &h->ws_tmp, &h->ws_tmp2, &h->ws_D1, &h->ws_I1, &h->ws_tmp3};
+        DevBuf *bufs[] = {&h->ws_flag, &h->ws_q, &h->ws_qn, &h->ws_lists, &h->ws_D, &h->ws_I, &h->ws_tmp, &h->ws_tmp2, &h->ws_D1, &h->ws_I1, &h->ws_tmp3};
         for (DevBuf *b : bufs) b->release();
-        for (DevBuf &b : h->ws_level) b.release();
+        for (LevelBufs &b : h->ws_level) {
+            b.qlist.release();
+            b.qcnt.release();
+            b.gthr.release();
+            b.qthr.release();
+        }
         for (int i = 0; i < knn_index_s::RING; i++) {
             if (h->ring0[i]) (void)hipEventDestroy(h->ring0[i]);
             if (h->ring1[i]) (void)hipEventDestroy(h->ring1[i]);
         }
         if (h->stream) (void)hipStreamDestroy(h->stream);
+        if (h->flag_host) (void)hipHostFree(h->flag_host);
     }
     delete h;
 }
@@ -1491,10 +1577,10 @@ extern "C" int knn_flat_reconstruct(knn_handle h, int64_t i0, int64_t n, float *
 }
 
 // ---- search ---------------------------------------------------------------
-// Per-chunk survivor slots: chunks stop at "at most 1.25 k" keys (the merge is exact).  The
-// register select serves k <= 1536 (in the scan kernels lists of <= 2048 keys, 32 per lane, so
-// that 1.25 k + one tile fits; in the merge two slots per wave, <= 4096 keys); beyond that the
-// workgroup-sort paths take exactly k.
+// A chunk hands on at most kslot = 1.25 k keys per query (k for k > 1536); the final selection
+// is exact.  The register select inside the scan kernels serves k <= 1536 (lists of <= 2048
+// keys, 32 per lane, so that 1.25 k + one tile fits); beyond that the workgroup sort takes
+// exactly k.
 static const int KNN_WAVE_SELECT_MAX_K = 1536;
 static int knn_kslot(int k) { return k > KNN_WAVE_SELECT_MAX_K ? k : k + k / 4; }
 
@@ -1505,76 +1591,17 @@ static int next_pow2_host(int n)
     return p;
 }
 
-// Runs merge rounds over `in` (L lists of kin >= k keys per query) until one list is left;
-// the last round sorts and writes keys_out (may be null; per-query stride keys_out_stride,
-// slots k..keys_out_fill padded) and/or D/I (may be null).  tmp0/tmp1: ping-pong buffers.
-static int run_merge(const uint64_t *in, int L, int kin, int k, int64_t nq, bool list_major, DevBuf &tmp0, DevBuf &tmp1,
-                     uint64_t *keys_out, int metric, float *D, int64_t *I, hipStream_t s, int64_t keys_out_stride = 0,
-                     int keys_out_fill = 0)
+// one workgroup per query: best k of its candidate keys (see select_topk_kernel)
+static int launch_select(SelectParams sp, hipStream_t s)
 {
-    if (keys_out_stride == 0) keys_out_stride = k;
-    const size_t lds_final = (size_t)4 * next_pow2_host(k) * 8;
-    bool lm = list_major;
-    int round = 0;
-    for (;;) {
-        // wave path: two or more lists must fit one register select (4096 keys); otherwise
-        // (k > 1536) the workgroup sort handles up to 8192 keys per group
-        const bool wave_path = 2 * kin <= 4096;
-        const int G = wave_path ? std::max(2, 4096 / kin) : std::max(2, 8192 / kin);
-        const int Lout = (L + G - 1) / G;
-        const bool final_round = Lout == 1;
-        uint64_t *out = nullptr;
-        if (!final_round) {
-            DevBuf &b = (round & 1) ? tmp1 : tmp0;
-            if (b.ensure((size_t)nq * Lout * k * 8)) return set_err(KNN_ERR_HIP, "merge: out of device memory");
-            out = (uint64_t *)b.p;
-        } else {
-            out = keys_out;
-        }
-        const int64_t items = nq * Lout;
-        if (wave_path) {
-            const unsigned grid = (unsigned)((items + 3) / 4);
-            const size_t lds = final_round ? lds_final : 0;
-            const int rneed = (std::min(L, G) * kin + 63) / 64; // keys per lane of the fullest wave
-            auto launch = [&](auto lm_tag, auto r_tag) {
-                hipLaunchKernelGGL((merge_select_kernel<decltype(lm_tag)::value, decltype(r_tag)::value>), dim3(grid), dim3(256), lds, s, in, L,
-                                   kin, k, nq, G, Lout, out, final_round ? keys_out_stride : (int64_t)0, keys_out_fill,
-                                   final_round ? 1 : 0, metric, D, I);
-            };
-            using T_ = std::true_type;
-            using F_ = std::false_type;
-            using R16 = std::integral_constant<int, 16>;
-            using R32 = std::integral_constant<int, 32>;
-            using R64 = std::integral_constant<int, 64>;
-            if (lm) {
-                if (rneed <= 16) launch(T_{}, R16{});
-                else if (rneed <= 32) launch(T_{}, R32{});
-                else launch(T_{}, R64{});
-            } else {
-                if (rneed <= 16) launch(F_{}, R16{});
-                else if (rneed <= 32) launch(F_{}, R32{});
-                else launch(F_{}, R64{});
-            }
-        } else {
-            const size_t lds = (size_t)next_pow2_host(std::min(L, G) * kin) * 8;
-            if (lm) {
-                HIP_TRY(hipFuncSetAttribute((const void *)merge_sort_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(merge_sort_kernel<true>, dim3((unsigned)items), dim3(256), lds, s, in, L, kin, k, nq, G, Lout, out,
-                                   final_round ? keys_out_stride : (int64_t)0, keys_out_fill, final_round ? 1 : 0, metric, D, I);
-            } else {
-                HIP_TRY(hipFuncSetAttribute((const void *)merge_sort_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(merge_sort_kernel<false>, dim3((unsigned)items), dim3(256), lds, s, in, L, kin, k, nq, G, Lout, out,
-                                   final_round ? keys_out_stride : (int64_t)0, keys_out_fill, final_round ? 1 : 0, metric, D, I);
-            }
-        }
-        HIP_TRY(hipGetLastError());
-        if (final_round) return 0;
-        in = out;
-        L = Lout;
-        kin = k;
-        lm = false;
-        round++;
-    }
+    if (sp.nq <= 0) return 0;
+    const int kmax = sp.k + std::max(sp.k >> 2, 32);
+    const size_t lds = (size_t)next_pow2_host(kmax) * 8;
+    const int nmax = sp.lm_lists > 0 ? sp.lm_lists * sp.lm_k : (sp.cnt ? sp.cap : sp.n_fixed);
+    void (*kern)(SelectParams) = nmax <= 256 * 4 ? select_topk_kernel<4> : (nmax <= 256 * 16 ? select_topk_kernel<16> : select_topk_kernel<64>);
+    hipLaunchKernelGGL(kern, dim3((unsigned)sp.nq), dim3(256), lds, s, sp);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 struct ScanPlan {
@@ -1586,18 +1613,13 @@ struct ScanPlan {
 
 
 template <int WM, int WN, int TM, int TN>
-static int launch_scan_cfg(const knn_index_s *h, const ScanParams &p, const ScanPlan &plan, hipStream_t s, bool sample = false)
+static int launch_scan_cfg(const knn_index_s *h, const ScanParams &p, const ScanPlan &plan, hipStream_t s)
 {
     const bool l2 = h->metric == KNN_METRIC_L2;
     void (*kern)(ScanParams) = nullptr;
-    const bool nt = p.nqtiles == 1; // one query tile: rows are read once, non-temporal staging loads
-    if (sample) {
-        if (nt) kern = l2 ? flat_scan_kernel<WM, WN, TM, TN, true, true, true> : flat_scan_kernel<WM, WN, TM, TN, false, true, true>;
-        else kern = l2 ? flat_scan_kernel<WM, WN, TM, TN, true, true, false> : flat_scan_kernel<WM, WN, TM, TN, false, true, false>;
-    } else {
-        if (nt) kern = l2 ? flat_scan_kernel<WM, WN, TM, TN, true, false, true> : flat_scan_kernel<WM, WN, TM, TN, false, false, true>;
-        else kern = l2 ? flat_scan_kernel<WM, WN, TM, TN, true, false, false> : flat_scan_kernel<WM, WN, TM, TN, false, false, false>;
-    }
+    // one query tile: rows are read once, non-temporal staging loads
+    if (p.nqtiles == 1) kern = l2 ? flat_scan_kernel<WM, WN, TM, TN, true, true> : flat_scan_kernel<WM, WN, TM, TN, false, true>;
+    else kern = l2 ? flat_scan_kernel<WM, WN, TM, TN, true, false> : flat_scan_kernel<WM, WN, TM, TN, false, false>;
     HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds));
     hipLaunchKernelGGL(kern, dim3(plan.grid), dim3(256), plan.lds, s, p);
     HIP_TRY(hipGetLastError());
@@ -1647,7 +1669,7 @@ static void make_plan(const knn_index_s *h, int64_t nb, int64_t nq, int k, bool 
     pl.chunk_rows = tiles_per * pl.dt;
     pl.nchunks = (int)((nb + pl.chunk_rows - 1) / pl.chunk_rows);
     pl.grid = pl.nqtiles * pl.nchunks;
-    pl.lds = std::max((size_t)2 * (pl.dt + pl.qt) * 128, (size_t)pl.cap * 8) + (size_t)qt * 8 + 16 + (size_t)pl.dt * 4;
+    pl.lds = std::max((size_t)2 * (pl.dt + pl.qt) * 128, (size_t)pl.cap * 8) + (size_t)qt * 12 + 16 + (size_t)pl.dt * 4;
 }
 
 // Seed stride of a view with nb rows: a power of two s such that the sample (every s-th 8-row block)
@@ -1663,62 +1685,121 @@ static int seed_stride(int64_t nb, int k, int64_t chunk_rows)
     return s;
 }
 
-// Exact top-k of the block-strided view (view_row) with stride row_mul for queries
-// [nq][dp] on the device.  Output: sorted keys (keys_out, per-query stride keys_stride) and/or D/I.
-static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int64_t nq, int k, uint32_t id_base, int row_mul,
-                       int level, uint64_t *keys_out, int64_t keys_stride, int keys_fill, float *D_out, int64_t *I_out,
-                       hipStream_t s)
+// Statistical seed (batch regime).  The exact seed above needs a sample of >= k rows whose k-th
+// score is a PROVEN bound of the global k-th: with k = 301 of 14433 rows no affordable sample gives a
+// useful one, every chunk warms up on its own and half of all scores go through the candidate lists.
+// Instead: T = the j-th best score of a sample of S rows, j << k chosen so that, were the sample
+// drawn at random, fewer than k of the N rows beat T with probability <= 1e-9 per query
+// (P[Binomial(S, k/N) >= j] <= 1e-9).  Every chunk filters with T from its first tile on (about
+// j N / S candidates per query instead of ~ chunks x k (1 + ln(rows per chunk / k))).  T is only
+// an estimate, so the result is VERIFIED: the final selection checks that the k-th score it found is
+// <= T -- then at least k rows beat T, all of them were candidates, and the result is exact.  A
+// query that fails the check raises a flag and the search is redone without the estimate (the
+// caller must be able to wait for the flag: synchronous entry points only).
+static int stat_seed_rank(int64_t S, int64_t N, int k)
 {
-    const int64_t nb = view_rows(h->ntotal, row_mul);
+    if (S < 64 || N <= 0 || k >= N) return -1;
+    const double pr = (double)k / (double)N, eps = 1e-9;
+    // smallest j with P[Bin(S, pr) >= j] <= eps: walk the pmf upwards, accumulating the lower tail
+    const double lp = log(pr), lq = log1p(-pr);
+    double cdf = 0.0;
+    const int64_t jmax = std::min<int64_t>(S, k);
+    for (int64_t i = 0; i <= jmax; i++) {
+        if (1.0 - cdf <= eps) return i >= 1 ? (int)i : 1; // P[X >= i] = 1 - P[X <= i-1]
+        cdf += exp(lgamma((double)S + 1.0) - lgamma((double)i + 1.0) - lgamma((double)(S - i) + 1.0) + (double)i * lp + (double)(S - i) * lq);
+    }
+    return -1; // would need more than min(S, k) sample hits: no statistical seed
+}
+
+// where the result of a (view) search goes
+struct SearchOut {
+    uint64_t *keys = nullptr; // sorted keys, k per query
+    int64_t keys_stride = 0;
+    int keys_fill = 0;
+    float *D = nullptr;
+    int64_t *I = nullptr;
+    // seeding the enclosing search (see SelectParams)
+    uint32_t *seed_cnt = nullptr, *seed_gthr = nullptr, *seed_qthr = nullptr;
+    int seed_j = 0, seed_stat = 0;
+};
+
+// Exact top-k of the block-strided view (view_row) with stride row_mul / block shift vshift for
+// queries [nq][dp] on the device.  allow_stat: the caller checks h->ws_flag afterwards.
+static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int64_t nq, int k, uint32_t id_base, int row_mul,
+                       int vshift, int level, const SearchOut &out, bool allow_stat, hipStream_t s)
+{
+    const int64_t nb = view_rows(h->ntotal, row_mul, vshift);
     ScanPlan pl;
     make_plan(h, nb, nq, k, true, pl);
-    if (level >= (int)(sizeof(h->ws_level) / sizeof(h->ws_level[0]))) return set_err(KNN_ERR_INVALID, "search: seed recursion too deep");
-    // Seeding pays when the sample that gives every chunk a tight threshold (about two chunks'
+    if (level >= knn_index_s::MAX_LEVELS) return set_err(KNN_ERR_INVALID, "search: seed recursion too deep");
+    // Exact seeding pays when the sample that gives every chunk a tight threshold (about two chunks'
     // worth of rows, at least 64 k) is a small fraction of the view: the streaming regime (few
-    // queries, huge database, hundreds of chunks).  Batch searches have few long chunks that
-    // amortise their own warm-up.  flags & 8 turns it off, flags & 16 forces it (tests).
+    // queries, huge database, hundreds of chunks).  flags & 8 turns all seeding off, flags & 16
+    // forces the exact seed, flags & 128 forces the statistical one, flags & 512 forbids it (tests).
     bool seed = nb >= 512 * (int64_t)k && std::max<int64_t>(2 * pl.chunk_rows, 64 * (int64_t)k) <= nb / 32;
     if (h->flags & 16) seed = nb >= 8192 && nb >= 32 * (int64_t)k;
-    if (h->flags & 8) seed = false;
-    if (!seed) make_plan(h, nb, nq, k, level > 0, pl); // a seed sample is small: parallelism over warm-up
-    const int sstride = seed ? seed_stride(nb, k, pl.chunk_rows) : 0;
-    // Keys per (query, chunk) slot.  Chunks of a single tile (a seed sample, a tiny database)
-    // hand ALL their rows to the merge: cutting 32 lists of one tile down to 1.25 k at the end
-    // of the only tile is serial work per workgroup (8 selects per wave, ~40 us) that the merge's
-    // first round does anyway, with one wave per (query, group).
+    if (h->flags & (8 | 128)) seed = false;
+    int sstride = seed ? seed_stride(nb, k, pl.chunk_rows) : 0;
+    int seed_j = k, seed_stat = 0, svshift = vshift;
+    if (!seed && allow_stat && level == 0 && row_mul == 1 && !(h->flags & (8 | 16 | 512))) {
+        // statistical seed: single rows, every 32nd (every 16th of a small database, every 64th of a
+        // large one): a few percent of the work, one round of workgroups at CATH size
+        const int st = nb >= (1 << 20) ? 64 : (nb >= 8192 ? 32 : 16);
+        const bool force = (h->flags & 128) != 0;
+        const int64_t S = view_rows(nb, st, 0);
+        const int j = stat_seed_rank(S, nb, k);
+        if (j > 0 && (force || (nq >= 1024 && nb >= 8192))) {
+            // worth it only if it removes most of the candidates an unseeded pass would collect
+            ScanPlan un;
+            make_plan(h, nb, nq, k, false, un);
+            const double unseeded = (double)un.nchunks * k * (1.0 + log(std::max(1.0, (double)un.chunk_rows / k)));
+            const double seeded = (double)j * (double)nb / (double)S;
+            if (force || seeded <= 0.5 * unseeded) {
+                sstride = st;
+                seed_j = j;
+                seed_stat = 1;
+                svshift = 0;
+            }
+        }
+    }
+    if (!sstride) make_plan(h, nb, nq, k, level > 0, pl); // a seed sample is small: parallelism over warm-up
+    // Most keys a chunk hands on per query.  Chunks of a single tile (a seed sample, a tiny database)
+    // hand on ALL their candidates: cutting 32 lists of one tile down to 1.25 k at the end of the only
+    // tile is serial work per workgroup that the final selection does anyway, one workgroup per query.
     int kslot = knn_kslot(k);
     if (pl.chunk_rows == pl.dt && pl.dt > kslot && pl.dt <= pl.cap - pl.dt && k <= KNN_WAVE_SELECT_MAX_K) kslot = pl.dt;
-    const int nlists = pl.nchunks + (sstride ? 1 : 0);
-    DevBuf &pbuf = h->ws_level[level];
-    if (pbuf.ensure((size_t)nq * nlists * kslot * 8)) return set_err(KNN_ERR_HIP, "search: out of device memory");
-    uint64_t *partial = (uint64_t *)pbuf.p;
+    const int qcap = pl.nchunks * kslot + (sstride ? k : 0);
+    LevelBufs &lb = h->ws_level[level];
+    const size_t nslots = (size_t)pl.nqtiles * pl.qt;
+    if (lb.qlist.ensure((size_t)nq * qcap * 8) || lb.qcnt.ensure((size_t)nq * 4) || lb.gthr.ensure(nslots * 4) || lb.qthr.ensure((size_t)nq * 4))
+        return set_err(KNN_ERR_HIP, "search: out of device memory");
+    uint64_t *qlist = (uint64_t *)lb.qlist.p;
+    uint32_t *qcnt = (uint32_t *)lb.qcnt.p, *gthr = (uint32_t *)lb.gthr.p, *qthr = (uint32_t *)lb.qthr.p;
     int rc;
+    HIP_TRY(hipMemsetAsync(gthr, 0xFF, nslots * 4, s));
     if (sstride) {
-        // the sample's sorted top-k lands in list slot nchunks of every query
-        rc = search_view(h, q_dev, xn, nq, k, id_base, row_mul * sstride, level + 1, partial + (size_t)pl.nchunks * kslot,
-                         (int64_t)nlists * kslot, kslot, nullptr, nullptr, s);
+        // the sample's sorted top-k opens every query's candidate array; its seed_j-th score is the
+        // running threshold the main pass starts from
+        SearchOut so;
+        so.keys = qlist; so.keys_stride = qcap; so.keys_fill = 0;
+        so.seed_cnt = qcnt; so.seed_gthr = gthr; so.seed_qthr = qthr; so.seed_j = seed_j; so.seed_stat = seed_stat;
+        rc = search_view(h, q_dev, xn, nq, k, id_base, row_mul * sstride, svshift, level + 1, so, false, s);
         if (rc) return rc;
-    }
-    if (h->ws_lists.ensure((size_t)pl.grid * pl.qt * pl.cap * 8) || h->ws_gthr.ensure((size_t)pl.nqtiles * pl.qt * 4))
-        return set_err(KNN_ERR_HIP, "search: out of device memory (candidate lists)");
-    if (sstride) {
-        const int64_t nslots = (int64_t)pl.nqtiles * pl.qt;
-        hipLaunchKernelGGL(seed_thresholds_kernel, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, s,
-                           (const uint64_t *)(partial + (size_t)pl.nchunks * kslot), (int64_t)nlists * kslot, k, nq, nslots,
-                           (uint32_t *)h->ws_gthr.p);
-        HIP_TRY(hipGetLastError());
     } else {
-        HIP_TRY(hipMemsetAsync(h->ws_gthr.p, 0xFF, (size_t)pl.nqtiles * pl.qt * 4, s));
+        HIP_TRY(hipMemsetAsync(qcnt, 0, (size_t)nq * 4, s));
+        HIP_TRY(hipMemsetAsync(qthr, 0xFF, (size_t)nq * 4, s));
     }
+    if (h->ws_lists.ensure((size_t)pl.grid * pl.qt * pl.cap * 8)) return set_err(KNN_ERR_HIP, "search: out of device memory (candidate lists)");
     ScanParams p;
     p.xb = h->xb; p.yn = h->yn; p.xq = q_dev; p.xn = xn;
     p.nb = nb; p.nq = nq; p.dp = h->dp; p.k = k; p.cap = pl.cap;
     p.nqtiles = pl.nqtiles; p.nchunks = pl.nchunks; p.chunk_rows = pl.chunk_rows;
-    p.lists = (uint64_t *)h->ws_lists.p; p.gthr = (uint32_t *)h->ws_gthr.p; p.partial = partial;
+    p.lists = (uint64_t *)h->ws_lists.p; p.gthr = gthr;
+    p.qlist = qlist; p.qcnt = qcnt; p.qcap = qcap;
     p.id_base = id_base;
     p.row_mul = row_mul;
+    p.vshift = sstride ? svshift : vshift;
     p.skip_mask = sstride ? sstride - 1 : -1;
-    p.partial_lists = nlists;
     p.kslot = kslot;
     const bool top = level == 0;
     if (top) {
@@ -1732,23 +1813,32 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
         h->nlaunches++;
         HIP_TRY(hipEventRecord(h->ev0, s));
     }
-    if (pl.qt == 128) rc = launch_scan_cfg<2, 2, 2, 2>(h, p, pl, s, !top);
-    else if (pl.qt == 64) rc = launch_scan_cfg<2, 2, 2, 1>(h, p, pl, s, !top);
-    else rc = launch_scan_cfg<4, 1, 2, 1>(h, p, pl, s, !top);
+    if (pl.qt == 128) rc = launch_scan_cfg<2, 2, 2, 2>(h, p, pl, s);
+    else if (pl.qt == 64) rc = launch_scan_cfg<2, 2, 2, 1>(h, p, pl, s);
+    else rc = launch_scan_cfg<4, 1, 2, 1>(h, p, pl, s);
     if (rc) return rc;
     if (top) {
         HIP_TRY(hipEventRecord(h->ev1, s));
         h->last_kernel = pl.name; h->last_qt = pl.qt; h->last_dt = pl.dt; h->last_chunks = pl.nchunks; h->last_grid = pl.grid;
         h->last_seed_stride = sstride;
+        h->last_seed_stat = seed_stat ? seed_j : 0;
     }
-    // merge rounds: per-chunk survivor lists (+ the seed list) -> sorted top-k (+ D/I)
-    return run_merge(partial, nlists, kslot, k, nq, false, h->ws_partial2, h->ws_tmp, keys_out, h->metric, D_out, I_out, s,
-                     keys_stride, keys_fill);
+    // final selection: every query's candidates (seed list + the chunks' survivors) -> sorted top-k
+    SelectParams sp = {};
+    sp.in = qlist; sp.in_stride = qcap; sp.cnt = qcnt; sp.cap = qcap;
+    sp.nq = nq; sp.k = k; sp.metric = h->metric;
+    sp.out_keys = out.keys; sp.out_stride = out.keys ? out.keys_stride : 0; sp.out_fill = out.keys_fill;
+    sp.D = out.D; sp.I = out.I;
+    sp.seed_cnt = out.seed_cnt; sp.seed_gthr = out.seed_gthr; sp.seed_qthr = out.seed_qthr; sp.seed_j = out.seed_j; sp.seed_stat = out.seed_stat;
+    sp.qthr = qthr; sp.fail = (int *)h->ws_flag.p;
+    return launch_select(sp, s);
 }
 
-// queries [nq][dp] already on device (padded); writes sorted keys [nq][k] and/or D/I
+// queries [nq][dp] already on device (padded); writes sorted keys [nq][k] and/or D/I.
+// allow_stat: the caller reads the fail flag once the stream has drained (search_failed) and repeats
+// the search with allow_stat = false if it is set.
 static int search_keys_impl(knn_index_s *h, const float *q_dev, int64_t nq, int k, uint32_t id_base,
-                            uint64_t *keys_out, float *D_out, int64_t *I_out, hipStream_t s)
+                            uint64_t *keys_out, float *D_out, int64_t *I_out, bool allow_stat, hipStream_t s)
 {
     const float *xn = nullptr;
     if (h->metric == KNN_METRIC_L2) {
@@ -1757,7 +1847,12 @@ static int search_keys_impl(knn_index_s *h, const float *q_dev, int64_t nq, int 
         if (rc) return rc;
         xn = (const float *)h->ws_qn.p;
     }
-    return search_view(h, q_dev, xn, nq, k, id_base, 1, 0, keys_out, k, 0, D_out, I_out, s);
+    if (h->ws_flag.ensure(64)) return set_err(KNN_ERR_HIP, "search: out of device memory");
+    HIP_TRY(hipMemsetAsync(h->ws_flag.p, 0, 4, s));
+    SearchOut out;
+    out.keys = keys_out; out.keys_stride = k; out.keys_fill = 0;
+    out.D = D_out; out.I = I_out;
+    return search_view(h, q_dev, xn, nq, k, id_base, 1, 3, 0, out, allow_stat, s);
 }
 
 static int check_search_args(knn_index_s *h, const void *q, int64_t nq, int64_t k, const void *D, const void *I)
@@ -1772,26 +1867,28 @@ static int check_search_args(knn_index_s *h, const void *q, int64_t nq, int64_t 
     return 0;
 }
 
-static int fill_empty(knn_index_s *h, float *D, int64_t *I, int64_t total, hipStream_t s)
+// index with no rows: every slot is unfilled
+__global__ void fill_empty_kernel(int64_t total, int metric, uint64_t *__restrict__ keys, float *__restrict__ D, int64_t *__restrict__ I)
 {
-    // index with no rows: every slot is unfilled
-    if (h->ws_keys.ensure((size_t)total * 8)) return set_err(KNN_ERR_HIP, "search: out of device memory");
-    HIP_TRY(hipMemsetAsync(h->ws_keys.p, 0xFF, (size_t)total * 8, s));
-    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
-                       (const uint64_t *)h->ws_keys.p, total, h->metric, D, I);
-    HIP_TRY(hipGetLastError());
-    return 0;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    if (keys) keys[i] = KEY_PAD;
+    if (D) {
+        D[i] = metric == KNN_METRIC_INNER_PRODUCT ? -FLT_MAX : FLT_MAX;
+        I[i] = -1;
+    }
 }
 
 // q_dev: [nq][d] contiguous on device. D_dev/I_dev on device.
 static int search_dev_impl(knn_index_s *h, const float *q_dev, int64_t nq, int k, float *D_dev, int64_t *I_dev,
-                           uint64_t *keys_dev, uint32_t id_base, hipStream_t s)
+                           uint64_t *keys_dev, uint32_t id_base, bool allow_stat, hipStream_t s)
 {
     if (nq == 0) return 0;
     const int64_t total = nq * k;
     if (h->ntotal == 0) {
-        if (keys_dev) { HIP_TRY(hipMemsetAsync(keys_dev, 0xFF, (size_t)total * 8, s)); return 0; }
-        return fill_empty(h, D_dev, I_dev, total, s);
+        hipLaunchKernelGGL(fill_empty_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, h->metric, keys_dev, D_dev, I_dev);
+        HIP_TRY(hipGetLastError());
+        return 0;
     }
     const float *qp = q_dev;
     if (h->dp != h->d) {
@@ -1802,7 +1899,19 @@ static int search_dev_impl(knn_index_s *h, const float *q_dev, int64_t nq, int k
         HIP_TRY(hipGetLastError());
         qp = (const float *)h->ws_q.p;
     }
-    return search_keys_impl(h, qp, nq, k, id_base, keys_dev, D_dev, I_dev, s);
+    return search_keys_impl(h, qp, nq, k, id_base, keys_dev, D_dev, I_dev, allow_stat, s);
+}
+
+// after the stream has drained: did a statistically seeded search fail its verification?
+static int search_failed(knn_index_s *h, bool *failed)
+{
+    *failed = false;
+    if (!h->ws_flag.p || h->ntotal == 0) return 0;
+    int flag = 0;
+    HIP_TRY(hipMemcpy(&flag, h->ws_flag.p, 4, hipMemcpyDeviceToHost));
+    *failed = flag != 0;
+    if (flag) h->stat_redo++;
+    return 0;
 }
 
 extern "C" int knn_flat_search_dev(knn_handle h, const float *q_dev, int64_t nq, int64_t k, float *D_dev,
@@ -1814,9 +1923,22 @@ extern "C" int knn_flat_search_dev(knn_handle h, const float *q_dev, int64_t nq,
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     h->last_ms = -1.f;
-    rc = search_dev_impl(h, q_dev, nq, (int)k, D_dev, I_dev, nullptr, 0, s);
+    // a caller's stream means "enqueue and return": no way to look at the verification flag, so
+    // only the synchronous form may use the statistical seed
+    const bool sync = stream == nullptr;
+    rc = search_dev_impl(h, q_dev, nq, (int)k, D_dev, I_dev, nullptr, 0, sync, s);
     if (rc) return rc;
-    if (!stream) HIP_TRY(hipStreamSynchronize(s));
+    if (sync) {
+        HIP_TRY(hipStreamSynchronize(s));
+        bool failed = false;
+        rc = search_failed(h, &failed);
+        if (rc) return rc;
+        if (failed) {
+            rc = search_dev_impl(h, q_dev, nq, (int)k, D_dev, I_dev, nullptr, 0, false, s);
+            if (rc) return rc;
+            HIP_TRY(hipStreamSynchronize(s));
+        }
+    }
     return 0;
 }
 
@@ -1829,7 +1951,7 @@ extern "C" int knn_flat_search_keys_dev(knn_handle h, const float *q_dev, int64_
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     h->last_ms = -1.f;
-    rc = search_dev_impl(h, q_dev, nq, (int)k, nullptr, nullptr, keys_dev, id_base, s);
+    rc = search_dev_impl(h, q_dev, nq, (int)k, nullptr, nullptr, keys_dev, id_base, false, s);
     if (rc) return rc;
     if (!stream) HIP_TRY(hipStreamSynchronize(s));
     return 0;
@@ -1845,9 +1967,12 @@ extern "C" int knn_merge_keys_dev(knn_handle h, const uint64_t *keys_dev, int32_
     std::lock_guard<std::mutex> lk(h->mu);
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
-    // intermediate rounds (nlists > 4096/k, e.g. 8 shards at k = 1000) use scratch owned by THIS handle:
-    // two lanes merging on two streams never share it
-    int rc = run_merge(keys_dev, nlists, (int)k, (int)k, nq, true, h->ws_merge0, h->ws_merge1, nullptr, h->metric, D_dev, I_dev, s);
+    // one launch whatever nlists * k is, no scratch memory: the selection reads the all-gather buffer in place
+    SelectParams sp = {};
+    sp.in = keys_dev; sp.lm_lists = nlists; sp.lm_k = (int)k;
+    sp.nq = nq; sp.k = (int)k; sp.metric = h->metric;
+    sp.D = D_dev; sp.I = I_dev;
+    int rc = launch_select(sp, s);
     if (rc) return rc;
     if (!stream) HIP_TRY(hipStreamSynchronize(s));
     return 0;
@@ -1889,19 +2014,33 @@ static int host_search(knn_index_s *h, const float *q_host, int64_t self_row0, i
     for (int i = 0; i < nslots; i++)
         if ((q_host && qbuf[i]->ensure((size_t)bq * h->d * 4)) || dbuf[i]->ensure((size_t)bq * k * 4) || ibuf[i]->ensure((size_t)bq * k * 8))
             return set_err(KNN_ERR_HIP, "search: out of device memory");
-    // one batch of queries on the device: uploaded rows ([m][d]) or the index's own rows ([m][dp])
-    auto scan = [&](int slot, int64_t b0, int64_t m) -> int {
+    if (!h->flag_host) HIP_TRY(hipHostMalloc((void **)&h->flag_host, 64, hipHostMallocDefault));
+    // one batch of queries on the device: uploaded rows ([m][d]) or the index's own rows ([m][dp]).
+    // The verification flag of a statistically seeded batch travels to flag_host[slot] behind it.
+    auto scan = [&](int slot, int64_t b0, int64_t m, bool allow_stat) -> int {
+        int r;
         if (q_host)
-            return search_dev_impl(h, (const float *)qbuf[slot]->p, m, (int)k, (float *)dbuf[slot]->p, (int64_t *)ibuf[slot]->p, nullptr, 0, h->stream);
-        return search_keys_impl(h, h->xb + (size_t)(self_row0 + b0) * h->dp, m, (int)k, 0, nullptr, (float *)dbuf[slot]->p,
-                                (int64_t *)ibuf[slot]->p, h->stream);
+            r = search_dev_impl(h, (const float *)qbuf[slot]->p, m, (int)k, (float *)dbuf[slot]->p, (int64_t *)ibuf[slot]->p, nullptr, 0, allow_stat, h->stream);
+        else
+            r = search_keys_impl(h, h->xb + (size_t)(self_row0 + b0) * h->dp, m, (int)k, 0, nullptr, (float *)dbuf[slot]->p,
+                                 (int64_t *)ibuf[slot]->p, allow_stat, h->stream);
+        if (r) return r;
+        h->flag_host[slot] = 0;
+        if (allow_stat && h->ntotal > 0) HIP_TRY(hipMemcpyAsync(&h->flag_host[slot], h->ws_flag.p, 4, hipMemcpyDeviceToHost, h->stream));
+        return 0;
     };
     // plain form: one batch at a time on the handle's stream (nothing to overlap with, or the
     // device's copy streams are taken)
-    auto plain = [&](int64_t b0, int64_t m) -> int {
+    auto plain = [&](int64_t b0, int64_t m, bool allow_stat) -> int {
         if (q_host) HIP_TRY(hipMemcpyAsync(qbuf[0]->p, q_host + b0 * h->d, (size_t)m * h->d * 4, hipMemcpyHostToDevice, h->stream));
-        int r = scan(0, b0, m);
+        int r = scan(0, b0, m, allow_stat);
         if (r) return r;
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (h->flag_host[0]) { // the statistical threshold was too tight for some query: once more without it
+            h->stat_redo++;
+            r = scan(0, b0, m, false);
+            if (r) return r;
+        }
         HIP_TRY(hipMemcpyAsync(D_host + b0 * k, dbuf[0]->p, (size_t)m * k * 4, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipMemcpyAsync(I_host + b0 * k, ibuf[0]->p, (size_t)m * k * 8, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1914,7 +2053,7 @@ static int host_search(knn_index_s *h, const float *q_host, int64_t self_row0, i
     if (nbatches == 1 || !pipes.try_lock()) {
         h->last_ms = 0.f;
         for (int64_t b0 = 0; b0 < nq; b0 += QB) {
-            rc = plain(b0, std::min(QB, nq - b0));
+            rc = plain(b0, std::min(QB, nq - b0), true);
             if (rc) return rc;
         }
         return 0;
@@ -1931,13 +2070,17 @@ static int host_search(knn_index_s *h, const float *q_host, int64_t self_row0, i
         std::thread th;
         hipError_t err = hipSuccess;
         hipEvent_t t0 = nullptr, t1 = nullptr; // scan events of the batch
+        int64_t batch = -1;
+        bool failed = false;
     } dl[2];
     float ms_total = 0.f;
     hipError_t dl_err = hipSuccess;
+    std::vector<int64_t> redo; // batches whose statistical threshold failed its verification
     auto join = [&](int slot) {
         if (!dl[slot].th.joinable()) return;
         dl[slot].th.join();
         if (dl[slot].err != hipSuccess) dl_err = dl[slot].err;
+        if (dl[slot].failed) redo.push_back(dl[slot].batch);
         float ms = 0.f;
         if (dl[slot].t0 && hipEventElapsedTime(&ms, dl[slot].t0, dl[slot].t1) == hipSuccess) ms_total += ms;
     };
@@ -1955,17 +2098,24 @@ static int host_search(knn_index_s *h, const float *q_host, int64_t self_row0, i
         const int64_t b0 = b * QB, m = std::min(QB, nq - b0);
         if (q_host) e = hipStreamWaitEvent(h->stream, cp.ev_query[slot], 0);
         if (e != hipSuccess) break;
-        rc = scan(slot, b0, m);
+        rc = scan(slot, b0, m, true);
         if (rc) break;
         e = hipEventRecord(cp.ev_batch[slot], h->stream);
         if (e != hipSuccess) break;
         dl[slot].t0 = h->ntotal > 0 ? h->ev0 : nullptr;
         dl[slot].t1 = h->ev1;
         dl[slot].err = hipSuccess;
+        dl[slot].batch = b;
+        dl[slot].failed = false;
         CopyPipes *cpp = &cp;
         dl[slot].th = std::thread([=, &dl]() {
             hipError_t r = hipSetDevice(h->device);
             if (r == hipSuccess) r = hipEventSynchronize(cpp->ev_batch[slot]);
+            if (r == hipSuccess && h->flag_host[slot]) {
+                dl[slot].failed = true; // repeated below, after the pipeline has drained
+                dl[slot].err = hipSuccess;
+                return;
+            }
             if (r == hipSuccess) r = hipMemcpyAsync(D_host + b0 * k, dbuf[slot]->p, (size_t)m * k * 4, hipMemcpyDeviceToHost, cpp->d2h);
             if (r == hipSuccess) r = hipMemcpyAsync(I_host + b0 * k, ibuf[slot]->p, (size_t)m * k * 8, hipMemcpyDeviceToHost, cpp->d2h);
             if (r == hipSuccess) r = hipStreamSynchronize(cpp->d2h);
@@ -1984,6 +2134,12 @@ static int host_search(knn_index_s *h, const float *q_host, int64_t self_row0, i
     if (dl_err != hipSuccess) return set_err(KNN_ERR_HIP, std::string("search: result download failed: ") + hipGetErrorString(dl_err));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->last_ms = ms_total;
+    for (int64_t b : redo) {
+        h->stat_redo++;
+        const int64_t b0 = b * QB;
+        rc = plain(b0, std::min(QB, nq - b0), false);
+        if (rc) return rc;
+    }
     return 0;
 }
 
@@ -2062,6 +2218,15 @@ extern "C" int32_t knn_scan_times(knn_handle h, float *out_ms, int32_t max_n)
         out_ms[i] = ms;
     }
     return (int32_t)n;
+}
+
+extern "C" int knn_last_seed_info(knn_handle h, int32_t *seed_stride, int32_t *stat_rank, int64_t *stat_redo)
+{
+    if (!h) return set_err(KNN_ERR_INVALID, "null handle");
+    if (seed_stride) *seed_stride = h->last_seed_stride;
+    if (stat_rank) *stat_rank = h->last_seed_stat;
+    if (stat_redo) *stat_redo = h->stat_redo;
+    return 0;
 }
 
 extern "C" int knn_flat_reserve(knn_handle h, int64_t nrows)

@@ -149,6 +149,13 @@ class IndexFlat(Index):
         return {"kernel": name.value.decode(), "query_tile": qt.value, "db_tile": dt.value, "nchunks": nc.value,
                 "grid": grid.value, "ms": float(L.knn_last_scan_ms(self._h))}
 
+    def last_seed(self):
+        """{"stride": seed-sample stride of the last search (0: none), "stat_rank": j of a statistical seed
+        (0: exact bound), "stat_redo": searches repeated because a statistical threshold failed verification}"""
+        st, j, redo = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64()
+        _lib.check(_lib.lib().knn_last_seed_info(self._h, ctypes.byref(st), ctypes.byref(j), ctypes.byref(redo)))
+        return {"stride": st.value, "stat_rank": j.value, "stat_redo": redo.value}
+
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:

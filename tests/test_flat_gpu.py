@@ -187,6 +187,89 @@ def test_sorted_database_never_overflows_lists(gpu_faiss, oracle, k, nq, metric)
         _assert_same(D, I, *oracle.flat_search(xb, xq, k, metric))
 
 
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("k", [10, 100, 301])
+def test_statistical_seed_matches_oracle(gpu_faiss, oracle, k, metric):
+    """flags=128 forces the statistical seed (batch regime: threshold = j-th score of a strided sample, j << k,
+    result verified against it): same bits as the oracle, through the host entry and through search_self."""
+    rng = np.random.default_rng(100 + k)
+    nb, d, nq = 20000, 64, 300
+    xb = rng.standard_normal((nb, d), dtype=np.float32)
+    xq = np.concatenate([rng.standard_normal((nq - 40, d), dtype=np.float32), xb[:40]])
+    idx = gpu_faiss.IndexFlat(d, metric)
+    idx.set_tuning(0, 0, 128)
+    idx.add(xb)
+    D, I = idx.search(xq, k)
+    seed = idx.last_seed()
+    assert seed["stride"] > 0 and 0 < seed["stat_rank"] < k, seed
+    _assert_same(D, I, *oracle.flat_search(xb, xq, k, metric))
+    Ds, Is = idx.search_self(k, 0, 500)
+    _assert_same(Ds, Is, *oracle.flat_search(xb, xb[:500], k, metric))
+    assert idx.last_seed()["stat_redo"] == 0
+
+
+def test_statistical_seed_is_automatic_in_the_batch_regime(gpu_faiss, oracle):
+    """>= 1024 queries against >= 8192 rows with a k that makes every chunk warm up on its own: the statistical
+    seed is chosen without being asked for; a caller stream (asynchronous entry) never uses it."""
+    import torch
+    from knn_for_homology_amd import _lib
+    rng = np.random.default_rng(7)
+    nb, d, nq, k = 16000, 48, 1100, 200
+    xb = rng.standard_normal((nb, d), dtype=np.float32)
+    xq = rng.standard_normal((nq, d), dtype=np.float32)
+    idx = gpu_faiss.IndexFlat(d, 1)
+    idx.add(xb)
+    D, I = idx.search(xq, k)
+    assert idx.last_seed()["stat_rank"] > 0
+    Do, Io = oracle.flat_search(xb, xq, k, 1)
+    _assert_same(D, I, Do, Io)
+    dev = torch.device("cuda:0")
+    q = torch.from_numpy(xq).to(dev)
+    Dd = torch.empty((nq, k), device=dev, dtype=torch.float32)
+    Id = torch.empty((nq, k), device=dev, dtype=torch.int64)
+    L = _lib.lib()
+    _lib.check(L.knn_flat_search_dev(idx._h, q.data_ptr(), nq, k, Dd.data_ptr(), Id.data_ptr(), None))  # synchronous: may use it
+    assert idx.last_seed()["stat_rank"] > 0
+    _assert_same(Dd.cpu().numpy(), Id.cpu().numpy(), Do, Io)
+    side = torch.cuda.Stream(dev)
+    with torch.cuda.stream(side):
+        import ctypes
+        _lib.check(L.knn_flat_search_dev(idx._h, q.data_ptr(), nq, k, Dd.data_ptr(), Id.data_ptr(), ctypes.c_void_p(side.cuda_stream)))
+    side.synchronize()
+    assert idx.last_seed()["stat_rank"] == 0 and idx.last_seed()["stride"] == 0
+    _assert_same(Dd.cpu().numpy(), Id.cpu().numpy(), Do, Io)
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_statistical_seed_failure_is_caught_and_repaired(gpu_faiss, oracle, metric):
+    """A database built against the sampler: exactly the sampled rows (every 32nd) are close to the queries, nothing
+    else is.  The j-th sample score then promises ~32 j rows that do not exist; the verification (k-th score found
+    <= threshold) must fail and the search must be repeated without the estimate -- exact result, stat_redo counts."""
+    rng = np.random.default_rng(55 + metric)
+    nb, d, nq, k = 16384, 64, 260, 100
+    base = rng.standard_normal(d).astype(np.float32)
+    base /= np.linalg.norm(base)
+    xb = rng.standard_normal((nb, d), dtype=np.float32)
+    xb /= np.linalg.norm(xb, axis=1, keepdims=True)
+    near = np.arange(0, nb, 32)
+    xb[near] = base[None, :] + 0.05 * rng.standard_normal((near.size, d)).astype(np.float32)
+    xq = (base[None, :] + 0.05 * rng.standard_normal((nq, d))).astype(np.float32)
+    idx = gpu_faiss.IndexFlat(d, metric)
+    idx.set_tuning(0, 0, 128)
+    idx.add(xb)
+    before = idx.last_seed()["stat_redo"]
+    D, I = idx.search(xq, k)
+    assert idx.last_seed()["stat_redo"] > before, "the adversarial sample must trip the verification"
+    _assert_same(D, I, *oracle.flat_search(xb, xq, k, metric))
+    assert np.isin(I[:, :50], near).all()
+    # pipelined multi-batch host path (> 16384 queries): failed batches are repeated after the pipeline drains
+    xq2 = np.concatenate([xq] * 70)[:17000]
+    D2, I2 = idx.search(xq2, k)
+    assert idx.last_seed()["stat_redo"] >= before + 3
+    _assert_same(D2[:nq], I2[:nq], D, I)
+    _assert_same(D2[-100:], I2[-100:], *oracle.flat_search(xb, xq2[-100:], k, metric))
+
+
 def test_normalize_matches_oracle(gpu_faiss, oracle):
     rng = np.random.default_rng(11)
     for n, d in ((1000, 1024), (333, 100), (50, 37), (1, 1024), (129, 8)):
