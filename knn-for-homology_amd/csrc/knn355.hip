@@ -852,6 +852,7 @@ struct SelectParams {
     int64_t in_stride;
     const uint32_t *cnt;
     int n_fixed, cap;
+    int n_expect;         // host's estimate of a typical count (0: cap) -- picks the build, any count is handled
     int lm_lists, lm_k;
     int64_t nq;
     int k, metric;
@@ -865,6 +866,7 @@ struct SelectParams {
     // statistical seed -- the same word as the bound its own result is verified against
     uint32_t *seed_cnt, *seed_gthr, *seed_qthr;
     int seed_j, seed_stat;
+    int64_t seed_nslots;  // threshold slots of the enclosing search (>= nq: the last query tile is padded)
     const uint32_t *qthr; // verification: a k-th score word above qthr[q] means the statistical threshold was too tight
     int *fail;
 };
@@ -888,18 +890,23 @@ __device__ __forceinline__ uint64_t wave_max_u64(uint64_t x)
     return x;
 }
 
-template <int R>
-__global__ __launch_bounds__(256) void select_topk_kernel(SelectParams p)
+// R keys per thread in registers, NT threads.  SEED: this is a seed sample's selection -- no sorted
+// output; it hands the enclosing search the sample's rows that beat T = the sample's seed_j-th
+// score (unsorted candidates, at most k of them), T itself as the running threshold and, for a
+// statistical seed, as the bound the enclosing result is verified against.
+template <int R, int NT, bool SEED>
+__global__ __launch_bounds__(NT) void select_topk_kernel(SelectParams p)
 {
+    constexpr int NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint64_t *sb = (uint64_t *)smem; // [P] survivors, sorted in place
-    __shared__ int s_red[2][4];
-    __shared__ int s_scan[4];
-    __shared__ uint64_t s_mm[2][4];
+    uint64_t *sb = (uint64_t *)smem; // [P] survivors, sorted in place (final mode)
+    __shared__ int s_red[2][NW];
+    __shared__ int s_scan[NW];
+    __shared__ uint64_t s_mm[2][NW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t q = blockIdx.x;
     const int k = p.k;
-    int n = p.lm_lists > 0 ? p.lm_lists * p.lm_k : (p.cnt ? (int)min(p.cnt[q], (uint32_t)p.cap) : p.n_fixed);
+    const int n = p.lm_lists > 0 ? p.lm_lists * p.lm_k : (p.cnt ? (int)min(p.cnt[q], (uint32_t)p.cap) : p.n_fixed);
     auto load = [&](int idx) -> uint64_t {
         if (p.lm_lists > 0) {
             const int l = idx / p.lm_k, j = idx - l * p.lm_k;
@@ -907,16 +914,32 @@ __global__ __launch_bounds__(256) void select_topk_kernel(SelectParams p)
         }
         return ((gptr_u64)p.in)[(size_t)q * p.in_stride + idx];
     };
-    const bool in_regs = n <= 256 * R;
+    const bool in_regs = n <= NT * R;
+    // memory path (more keys than the registers hold): several independent loads in flight per thread
+    auto for_each_mem = [&](auto &&fn) {
+        constexpr int U = NT >= 1024 ? 4 : 8; // (the 1024-thread build has 128 registers per lane)
+        int idx = tid;
+        for (; idx + (U - 1) * NT < n; idx += U * NT) {
+            uint64_t v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) v[u] = load(idx + u * NT);
+#pragma unroll
+            for (int u = 0; u < U; u++) fn(v[u]);
+        }
+        for (; idx < n; idx += NT) fn(load(idx));
+    };
     uint64_t key[R];
     uint64_t mn = KEY_PAD, mx = 0;
     int real = 0;
     if (in_regs) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const int idx = r * 256 + tid;
-            uint64_t v = load(idx < n ? idx : (n > 0 ? n - 1 : 0));
-            if (idx >= n) v = KEY_PAD;
+            const int idx = r * NT + tid;
+            uint64_t v = KEY_PAD;
+            if (r * NT < n) { // (uniform) registers past the end of a short array cost nothing
+                v = load(idx < n ? idx : n - 1);
+                if (idx >= n) v = KEY_PAD;
+            }
             key[r] = v;
             if (v != KEY_PAD) {
                 mn = v < mn ? v : mn;
@@ -925,14 +948,13 @@ __global__ __launch_bounds__(256) void select_topk_kernel(SelectParams p)
             }
         }
     } else {
-        for (int idx = tid; idx < n; idx += 256) {
-            const uint64_t v = load(idx);
+        for_each_mem([&](uint64_t v) {
             if (v != KEY_PAD) {
                 mn = v < mn ? v : mn;
                 mx = v > mx ? v : mx;
                 real++;
             }
-        }
+        });
     }
     mn = wave_min_u64(mn);
     mx = wave_max_u64(mx);
@@ -943,9 +965,13 @@ __global__ __launch_bounds__(256) void select_topk_kernel(SelectParams p)
         s_scan[wave] = real;
     }
     __syncthreads();
-    mn = min(min(s_mm[0][0], s_mm[0][1]), min(s_mm[0][2], s_mm[0][3]));
-    mx = max(max(s_mm[1][0], s_mm[1][1]), max(s_mm[1][2], s_mm[1][3]));
-    real = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
+    real = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < NW; w2++) {
+        mn = min(mn, s_mm[0][w2]);
+        mx = max(mx, s_mm[1][w2]);
+        real += s_scan[w2];
+    }
     __syncthreads(); // s_scan is reused below
 
     int par = 0;
@@ -953,116 +979,180 @@ __global__ __launch_bounds__(256) void select_topk_kernel(SelectParams p)
         int c = 0;
         if (in_regs) {
 #pragma unroll
-            for (int r = 0; r < R; r++) c += key[r] < X ? 1 : 0;
+            for (int r = 0; r < R; r++)
+                if (r * NT < n) c += key[r] < X ? 1 : 0; // (uniform: registers past the end hold padding)
         } else {
-            for (int idx = tid; idx < n; idx += 256) c += load(idx) < X ? 1 : 0;
+            for_each_mem([&](uint64_t v) { c += v < X ? 1 : 0; });
         }
         c = wave_sum(c);
         if (lane == 0) s_red[par][wave] = c;
         __syncthreads();
-        c = s_red[par][0] + s_red[par][1] + s_red[par][2] + s_red[par][3];
+        c = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < NW; w2++) c += s_red[par][w2];
         par ^= 1; // the next probe writes the other set: one barrier per probe is enough
         return c;
     };
-    const int kmax = k + max(k >> 2, 32);
-    int cnt = real;
-    uint64_t T = KEY_PAD; // survivors: keys < T (KEY_PAD: every real key)
-    if (real > kmax) {
-        uint64_t lo = mn, hi = mx + 1; // f(lo) = 0 < k, f(hi) = real > kmax
+    // X with klo <= #(keys < X) <= khi, or KEY_PAD when no more than khi real keys exist; *cnt_out = that count
+    auto bracket = [&](int klo, int khi, int *cnt_out) -> uint64_t {
+        if (real <= khi) {
+            *cnt_out = real;
+            return KEY_PAD;
+        }
+        uint64_t lo = mn, hi = mx + 1; // f(lo) = 0 < klo, f(hi) = real > khi
         int f_lo = 0, f_hi = real;
-        const double target = 0.5 * (double)(k + kmax);
+        const double target = 0.5 * (double)(klo + khi);
         bool interpolate = true;
-        for (int it = 0; it < 160; it++) {
+        for (int it = 0; it < 200; it++) {
             const uint64_t w = hi - lo;
-            if (w <= 1) { // cannot happen while the keys are distinct; keep the kmax best of the tie
-                T = hi;
-                cnt = f_hi;
-                break;
-            }
+            if (w <= 1) break; // cannot happen while the keys are distinct
             uint64_t X;
             if (interpolate) X = lo + (uint64_t)((double)w * ((target - (double)f_lo) / (double)(f_hi - f_lo)));
             else X = lo + (w >> 1);
             X = max(lo + 1, min(X, hi - 1));
             interpolate = !interpolate;
             const int c = count_lt(X);
-            if (c < k) {
+            if (c < klo) {
                 lo = X;
                 f_lo = c;
-            } else if (c > kmax) {
+            } else if (c > khi) {
                 hi = X;
                 f_hi = c;
             } else {
-                T = X;
-                cnt = c;
-                break;
+                *cnt_out = c;
+                return X;
             }
         }
-    }
-    // pack the survivors into LDS (positions from a workgroup-wide exclusive scan of the per-thread counts)
-    int P = 64;
-    while (P < cnt) P <<= 1;
-    const int Pcap = 1 << (32 - __builtin_clz(kmax - 1)); // what the host sized the LDS for: next_pow2(kmax)
-    if (P > Pcap) P = Pcap;
-    int mine = 0;
-    if (in_regs) {
+        *cnt_out = f_hi; // duplicate keys (never in a well-formed input): keep the tie, the caller clamps
+        return hi;
+    };
+    // position of this thread's first survivor in the packed output (workgroup-wide exclusive scan)
+    auto survivors_base = [&](uint64_t T) -> int {
+        int mine = 0;
+        if (in_regs) {
 #pragma unroll
-        for (int r = 0; r < R; r++) mine += key[r] < T ? 1 : 0;
-    } else {
-        for (int idx = tid; idx < n; idx += 256) mine += load(idx) < T ? 1 : 0;
-    }
-    const int incl = wave_inclusive_scan(mine);
-    if (lane == 63) s_scan[wave] = incl;
-    __syncthreads();
-    int pos = incl - mine;
-    for (int w2 = 0; w2 < wave; w2++) pos += s_scan[w2];
-    if (in_regs) {
-#pragma unroll
-        for (int r = 0; r < R; r++)
-            if (key[r] < T) {
-                if (pos < P) sb[pos] = key[r];
-                pos++;
-            }
-    } else {
-        for (int idx = tid; idx < n; idx += 256) {
-            const uint64_t v = load(idx);
-            if (v < T) {
-                if (pos < P) sb[pos] = v;
-                pos++;
-            }
+            for (int r = 0; r < R; r++)
+                if (r * NT < n) mine += key[r] < T ? 1 : 0;
+        } else {
+            for_each_mem([&](uint64_t v) { mine += v < T ? 1 : 0; });
         }
-    }
-    for (int i = cnt + tid; i < P; i += 256) sb[i] = KEY_PAD;
-    __syncthreads();
-    wg_bitonic_sort(sb, P, tid, 256);
-    cnt = min(cnt, P);
-    const int have = min(cnt, k); // real keys among the first k
-    for (int i = tid; i < max(k, p.out_fill); i += 256) {
-        const uint64_t v = i < have ? sb[i] : KEY_PAD;
-        if (p.out_keys) p.out_keys[(size_t)q * p.out_stride + i] = v;
-        if (p.D && i < k) {
-            const size_t o = (size_t)q * k + i;
-            if (v == KEY_PAD) {
-                p.D[o] = p.metric == KNN_METRIC_INNER_PRODUCT ? -FLT_MAX : FLT_MAX;
-                p.I[o] = -1;
+        const int incl = wave_inclusive_scan(mine);
+        if (lane == 63) s_scan[wave] = incl;
+        __syncthreads();
+        int pos = incl - mine;
+        for (int w2 = 0; w2 < wave; w2++) pos += s_scan[w2];
+        return pos;
+    };
+    auto pack = [&](uint64_t T, int pos, uint64_t *dst, int limit) {
+        if (in_regs) {
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                if (r * NT < n && key[r] < T) {
+                    if (pos < limit) dst[pos] = key[r];
+                    pos++;
+                }
+        } else {
+            for_each_mem([&](uint64_t v) {
+                if (v < T) {
+                    if (pos < limit) dst[pos] = v;
+                    pos++;
+                }
+            });
+        }
+    };
+
+    if constexpr (SEED) {
+        // T = the score word of a key of rank r in [seed_j, 1.25 seed_j] (any rank >= seed_j is a bound at least as
+        // safe as the seed_j-th, and a loose target converges in 3-5 probes where the exact rank takes dozens);
+        // the sample hands on every row that beats T (score word <= T: ties included, the main pass admits
+        // them too) -- at most kmax of them, the k best if more rows than that tie into the bound
+        const int kmax = k + max(k >> 2, 32);
+        int cj = 0;
+        uint32_t T = 0xFFFFFFFFu;
+        uint64_t Tkey = KEY_PAD;
+        int cnt = real;
+        if (real >= p.seed_j) {
+            const uint64_t Xj = bracket(p.seed_j, p.seed_j + max(p.seed_j >> 2, 8), &cj);
+            // the largest key below Xj carries the bound
+            uint64_t m = 0;
+            if (in_regs) {
+#pragma unroll
+                for (int r = 0; r < R; r++)
+                    if (r * NT < n) m = (key[r] < Xj && key[r] > m) ? key[r] : m;
             } else {
-                const float f = ord2f((uint32_t)(v >> 32));
-                p.D[o] = p.metric == KNN_METRIC_INNER_PRODUCT ? -f : f;
-                p.I[o] = (int64_t)(uint32_t)v;
+                for_each_mem([&](uint64_t v) { m = (v < Xj && v > m) ? v : m; });
+            }
+            m = wave_max_u64(m);
+            if (lane == 0) s_mm[0][wave] = m;
+            __syncthreads();
+#pragma unroll
+            for (int w2 = 0; w2 < NW; w2++) m = max(m, s_mm[0][w2]);
+            T = (uint32_t)(m >> 32);
+            Tkey = T == 0xFFFFFFFFu ? KEY_PAD : ((uint64_t)(T + 1u) << 32);
+            cnt = Tkey == KEY_PAD ? real : count_lt(Tkey);
+            if (cnt > kmax) Tkey = bracket(k, kmax, &cnt); // (heavy ties) the best k..kmax of them: no row beyond the k-th can matter
+        }
+        cnt = min(cnt, kmax);
+        const int pos = survivors_base(Tkey);
+        pack(Tkey, pos, p.out_keys + (size_t)q * p.out_stride, kmax);
+        if (tid == 0) {
+            p.seed_cnt[q] = (uint32_t)cnt;
+            p.seed_gthr[q] = T;
+            p.seed_qthr[q] = p.seed_stat ? T : 0xFFFFFFFFu;
+        }
+        // threshold slots of the padding queries of the last query tile (they mirror the last query and append nothing)
+        if (q == 0)
+            for (int64_t i = p.nq + tid; i < p.seed_nslots; i += NT) p.seed_gthr[i] = 0xFFFFFFFFu;
+        return;
+    } else {
+        const int kmax = k + max(k >> 2, 32);
+        int cnt = real;
+        const uint64_t T = bracket(k, kmax, &cnt); // survivors: keys < T (KEY_PAD: every real key)
+        int P = 64;
+        while (P < cnt) P <<= 1;
+        const int Pcap = 1 << (32 - __builtin_clz(kmax - 1)); // what the host sized the LDS for: next_pow2(kmax)
+        if (P > Pcap) P = Pcap;
+        const int pos = survivors_base(T);
+        pack(T, pos, sb, P);
+        for (int i = cnt + tid; i < P; i += NT) sb[i] = KEY_PAD;
+        __syncthreads();
+        wg_bitonic_sort(sb, P, tid, NT);
+        cnt = min(cnt, P);
+        const int have = min(cnt, k); // real keys among the first k
+        for (int i = tid; i < max(k, p.out_fill); i += NT) {
+            const uint64_t v = i < have ? sb[i] : KEY_PAD;
+            if (p.out_keys) p.out_keys[(size_t)q * p.out_stride + i] = v;
+            if (p.D && i < k) {
+                const size_t o = (size_t)q * k + i;
+                if (v == KEY_PAD) {
+                    p.D[o] = p.metric == KNN_METRIC_INNER_PRODUCT ? -FLT_MAX : FLT_MAX;
+                    p.I[o] = -1;
+                } else {
+                    const float f = ord2f((uint32_t)(v >> 32));
+                    p.D[o] = p.metric == KNN_METRIC_INNER_PRODUCT ? -f : f;
+                    p.I[o] = (int64_t)(uint32_t)v;
+                }
             }
         }
-    }
-    if (tid == 0) {
-        if (p.seed_cnt) {
-            const uint32_t thr = cnt >= p.seed_j ? (uint32_t)(sb[p.seed_j - 1] >> 32) : 0xFFFFFFFFu;
-            p.seed_cnt[q] = (uint32_t)have;
-            p.seed_gthr[q] = thr;
-            p.seed_qthr[q] = p.seed_stat ? thr : 0xFFFFFFFFu;
-        }
-        if (p.qthr && p.fail) {
+        if (tid == 0 && p.qthr && p.fail) {
             const uint32_t kth = cnt >= k ? (uint32_t)(sb[k - 1] >> 32) : 0xFFFFFFFFu;
             if (kth > p.qthr[q]) *p.fail = 1;
         }
     }
+}
+
+// (re)initialises a level's per-query state in one launch: running thresholds "no bound", empty candidate
+// arrays, no verification bound
+__global__ void init_level_kernel(uint32_t *__restrict__ gthr, int64_t nslots, uint32_t *__restrict__ qcnt,
+                                  uint32_t *__restrict__ qthr, int64_t nq, int *__restrict__ flag)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gthr && i < nslots) gthr[i] = 0xFFFFFFFFu;
+    if (qcnt && i < nq) {
+        qcnt[i] = 0u;
+        qthr[i] = 0xFFFFFFFFu;
+    }
+    if (flag && i == 0) *flag = 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -1595,11 +1685,34 @@ static int next_pow2_host(int n)
 static int launch_select(SelectParams sp, hipStream_t s)
 {
     if (sp.nq <= 0) return 0;
+    const bool seed = sp.seed_cnt != nullptr;
     const int kmax = sp.k + std::max(sp.k >> 2, 32);
-    const size_t lds = (size_t)next_pow2_host(kmax) * 8;
+    const size_t lds = seed ? 0 : (size_t)next_pow2_host(kmax) * 8;
     const int nmax = sp.lm_lists > 0 ? sp.lm_lists * sp.lm_k : (sp.cnt ? sp.cap : sp.n_fixed);
-    void (*kern)(SelectParams) = nmax <= 256 * 4 ? select_topk_kernel<4> : (nmax <= 256 * 16 ? select_topk_kernel<16> : select_topk_kernel<64>);
-    hipLaunchKernelGGL(kern, dim3((unsigned)sp.nq), dim3(256), lds, s, sp);
+    void (*kern)(SelectParams);
+    int nt = 256;
+    // Many queries with short candidate arrays (the batch regime): ONE WAVE per query -- four times the queries
+    // in flight per CU, and the kernel is bound by the latency of its dependent loads, not by arithmetic
+    // (14433 queries x ~1400 keys: 265 us with a workgroup per query).  Few queries with long arrays (the
+    // streaming regime): a workgroup per query, up to 32768 keys in registers.  Arrays longer than the
+    // registers of the chosen build hold are re-read from L2 on every probe.
+    const int nexp = sp.n_expect > 0 ? std::min(sp.n_expect, nmax) : nmax;
+    if (sp.nq >= 512 && nexp <= 64 * 32) {
+        nt = 64;
+        if (seed) kern = nexp <= 64 * 8 ? select_topk_kernel<8, 64, true> : select_topk_kernel<32, 64, true>;
+        else kern = nexp <= 64 * 8 ? select_topk_kernel<8, 64, false> : select_topk_kernel<32, 64, false>;
+    } else if (seed) {
+        if (nmax <= 256 * 4) kern = select_topk_kernel<4, 256, true>;
+        else if (nmax <= 256 * 16) kern = select_topk_kernel<16, 256, true>;
+        else if (nmax <= 256 * 32) kern = select_topk_kernel<32, 256, true>;
+        else { kern = select_topk_kernel<32, 1024, true>; nt = 1024; }
+    } else {
+        if (nmax <= 256 * 4) kern = select_topk_kernel<4, 256, false>;
+        else if (nmax <= 256 * 16) kern = select_topk_kernel<16, 256, false>;
+        else if (nmax <= 256 * 32) kern = select_topk_kernel<32, 256, false>;
+        else { kern = select_topk_kernel<32, 1024, false>; nt = 1024; }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)sp.nq), dim3(nt), lds, s, sp);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1721,6 +1834,7 @@ struct SearchOut {
     // seeding the enclosing search (see SelectParams)
     uint32_t *seed_cnt = nullptr, *seed_gthr = nullptr, *seed_qthr = nullptr;
     int seed_j = 0, seed_stat = 0;
+    int64_t seed_nslots = 0;
 };
 
 // Exact top-k of the block-strided view (view_row) with stride row_mul / block shift vshift for
@@ -1741,6 +1855,7 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     if (h->flags & (8 | 128)) seed = false;
     int sstride = seed ? seed_stride(nb, k, pl.chunk_rows) : 0;
     int seed_j = k, seed_stat = 0, svshift = vshift;
+    double expect_n = 0; // typical candidates per query at the final selection (0: unknown, assume the capacity)
     if (!seed && allow_stat && level == 0 && row_mul == 1 && !(h->flags & (8 | 16 | 512))) {
         // statistical seed: single rows, every 32nd (every 16th of a small database, every 64th of a
         // large one): a few percent of the work, one round of workgroups at CATH size
@@ -1759,6 +1874,7 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
                 seed_j = j;
                 seed_stat = 1;
                 svshift = 0;
+                expect_n = 1.3 * seeded + 1.25 * k; // (the bound's rank is in [j, 1.25 j]) + the sample's own rows
             }
         }
     }
@@ -1768,7 +1884,7 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     // tile is serial work per workgroup that the final selection does anyway, one workgroup per query.
     int kslot = knn_kslot(k);
     if (pl.chunk_rows == pl.dt && pl.dt > kslot && pl.dt <= pl.cap - pl.dt && k <= KNN_WAVE_SELECT_MAX_K) kslot = pl.dt;
-    const int qcap = pl.nchunks * kslot + (sstride ? k : 0);
+    const int qcap = pl.nchunks * kslot + (sstride ? k + std::max(k >> 2, 32) : 0); // (a seed sample hands on up to kmax keys)
     LevelBufs &lb = h->ws_level[level];
     const size_t nslots = (size_t)pl.nqtiles * pl.qt;
     if (lb.qlist.ensure((size_t)nq * qcap * 8) || lb.qcnt.ensure((size_t)nq * 4) || lb.gthr.ensure(nslots * 4) || lb.qthr.ensure((size_t)nq * 4))
@@ -1776,18 +1892,20 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     uint64_t *qlist = (uint64_t *)lb.qlist.p;
     uint32_t *qcnt = (uint32_t *)lb.qcnt.p, *gthr = (uint32_t *)lb.gthr.p, *qthr = (uint32_t *)lb.qthr.p;
     int rc;
-    HIP_TRY(hipMemsetAsync(gthr, 0xFF, nslots * 4, s));
     if (sstride) {
         // the sample's sorted top-k opens every query's candidate array; its seed_j-th score is the
         // running threshold the main pass starts from
         SearchOut so;
         so.keys = qlist; so.keys_stride = qcap; so.keys_fill = 0;
         so.seed_cnt = qcnt; so.seed_gthr = gthr; so.seed_qthr = qthr; so.seed_j = seed_j; so.seed_stat = seed_stat;
+        so.seed_nslots = (int64_t)nslots;
         rc = search_view(h, q_dev, xn, nq, k, id_base, row_mul * sstride, svshift, level + 1, so, false, s);
         if (rc) return rc;
     } else {
-        HIP_TRY(hipMemsetAsync(qcnt, 0, (size_t)nq * 4, s));
-        HIP_TRY(hipMemsetAsync(qthr, 0xFF, (size_t)nq * 4, s));
+        const int64_t nn = std::max<int64_t>((int64_t)nslots, nq);
+        hipLaunchKernelGGL(init_level_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, s, gthr, (int64_t)nslots, qcnt, qthr, nq,
+                           (int *)nullptr);
+        HIP_TRY(hipGetLastError());
     }
     if (h->ws_lists.ensure((size_t)pl.grid * pl.qt * pl.cap * 8)) return set_err(KNN_ERR_HIP, "search: out of device memory (candidate lists)");
     ScanParams p;
@@ -1826,10 +1944,13 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     // final selection: every query's candidates (seed list + the chunks' survivors) -> sorted top-k
     SelectParams sp = {};
     sp.in = qlist; sp.in_stride = qcap; sp.cnt = qcnt; sp.cap = qcap;
+    if (expect_n <= 0) expect_n = (double)qcap;
+    sp.n_expect = (int)std::min<double>(std::min<double>((double)qcap, expect_n), (double)nb); // (never more than the view has rows)
     sp.nq = nq; sp.k = k; sp.metric = h->metric;
     sp.out_keys = out.keys; sp.out_stride = out.keys ? out.keys_stride : 0; sp.out_fill = out.keys_fill;
     sp.D = out.D; sp.I = out.I;
     sp.seed_cnt = out.seed_cnt; sp.seed_gthr = out.seed_gthr; sp.seed_qthr = out.seed_qthr; sp.seed_j = out.seed_j; sp.seed_stat = out.seed_stat;
+    sp.seed_nslots = out.seed_nslots;
     sp.qthr = qthr; sp.fail = (int *)h->ws_flag.p;
     return launch_select(sp, s);
 }
