@@ -853,6 +853,8 @@ struct SelectParams {
     const uint32_t *cnt;
     int n_fixed, cap;
     int n_expect;         // host's estimate of a typical count (0: cap) -- picks the build, any count is handled
+    int seg_len, nseg;    // segment pass (nseg > 0): workgroup (q, s) selects among keys [s * seg_len, (s + 1) * seg_len) of query q
+                          // and writes output row q * nseg + s
     int lm_lists, lm_k;
     int64_t nq;
     int k, metric;
@@ -906,13 +908,20 @@ __global__ __launch_bounds__(NT) void select_topk_kernel(SelectParams p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t q = blockIdx.x;
     const int k = p.k;
-    const int n = p.lm_lists > 0 ? p.lm_lists * p.lm_k : (p.cnt ? (int)min(p.cnt[q], (uint32_t)p.cap) : p.n_fixed);
+    int n = p.lm_lists > 0 ? p.lm_lists * p.lm_k : (p.cnt ? (int)min(p.cnt[q], (uint32_t)p.cap) : p.n_fixed);
+    int seg_base = 0;
+    int64_t orow = q; // output row
+    if (p.nseg > 0) {
+        seg_base = (int)blockIdx.y * p.seg_len;
+        n = max(0, min(n - seg_base, p.seg_len));
+        orow = q * p.nseg + blockIdx.y;
+    }
     auto load = [&](int idx) -> uint64_t {
         if (p.lm_lists > 0) {
             const int l = idx / p.lm_k, j = idx - l * p.lm_k;
             return ((gptr_u64)p.in)[((size_t)l * p.nq + q) * p.lm_k + j];
         }
-        return ((gptr_u64)p.in)[(size_t)q * p.in_stride + idx];
+        return ((gptr_u64)p.in)[(size_t)q * p.in_stride + seg_base + idx];
     };
     const bool in_regs = n <= NT * R;
     // memory path (more keys than the registers hold): several independent loads in flight per thread
@@ -1121,7 +1130,7 @@ __global__ __launch_bounds__(NT) void select_topk_kernel(SelectParams p)
         const int have = min(cnt, k); // real keys among the first k
         for (int i = tid; i < max(k, p.out_fill); i += NT) {
             const uint64_t v = i < have ? sb[i] : KEY_PAD;
-            if (p.out_keys) p.out_keys[(size_t)q * p.out_stride + i] = v;
+            if (p.out_keys) p.out_keys[(size_t)orow * p.out_stride + i] = v;
             if (p.D && i < k) {
                 const size_t o = (size_t)q * k + i;
                 if (v == KEY_PAD) {
@@ -1681,10 +1690,35 @@ static int next_pow2_host(int n)
     return p;
 }
 
-// one workgroup per query: best k of its candidate keys (see select_topk_kernel)
-static int launch_select(SelectParams sp, hipStream_t s)
+// one workgroup per query: best k of its candidate keys (see select_topk_kernel).  tmp: scratch for the segment
+// pass of arrays longer than one workgroup's registers hold.
+static const int KNN_SELECT_SEG = 32768;
+static int launch_select(SelectParams sp, hipStream_t s, DevBuf *tmp = nullptr)
 {
     if (sp.nq <= 0) return 0;
+    if (tmp && sp.lm_lists == 0 && sp.cnt && sp.cap > KNN_SELECT_SEG) {
+        // Arrays of up to `cap` > 32768 keys (a seed sample of a 10 M-row database hands on 39 k scores per
+        // query): workgroup (q, s) reduces segment s of query q to its kk = kmax best keys in registers, then
+        // one more launch selects among the nseg * kk survivors -- two launches instead of re-reading the
+        // array from L2 on every probe.
+        const int kk = sp.k + std::max(sp.k >> 2, 32);
+        const int nseg = (sp.cap + KNN_SELECT_SEG - 1) / KNN_SELECT_SEG;
+        if (tmp->ensure((size_t)sp.nq * nseg * kk * 8)) return set_err(KNN_ERR_HIP, "search: out of device memory");
+        SelectParams a = {};
+        a.in = sp.in; a.in_stride = sp.in_stride; a.cnt = sp.cnt; a.cap = sp.cap;
+        a.seg_len = KNN_SELECT_SEG; a.nseg = nseg;
+        a.nq = sp.nq; a.k = kk; a.metric = sp.metric;
+        a.out_keys = (uint64_t *)tmp->p; a.out_stride = kk; a.out_fill = 0;
+        const size_t lds = (size_t)next_pow2_host(kk + std::max(kk >> 2, 32)) * 8;
+        hipLaunchKernelGGL((select_topk_kernel<32, 1024, false>), dim3((unsigned)sp.nq, (unsigned)nseg), dim3(1024), lds, s, a);
+        HIP_TRY(hipGetLastError());
+        sp.in = (const uint64_t *)tmp->p;
+        sp.in_stride = (int64_t)nseg * kk;
+        sp.cnt = nullptr;
+        sp.n_fixed = nseg * kk;
+        sp.cap = nseg * kk;
+        sp.n_expect = 0;
+    }
     const bool seed = sp.seed_cnt != nullptr;
     const int kmax = sp.k + std::max(sp.k >> 2, 32);
     const size_t lds = seed ? 0 : (size_t)next_pow2_host(kmax) * 8;
@@ -1952,7 +1986,7 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     sp.seed_cnt = out.seed_cnt; sp.seed_gthr = out.seed_gthr; sp.seed_qthr = out.seed_qthr; sp.seed_j = out.seed_j; sp.seed_stat = out.seed_stat;
     sp.seed_nslots = out.seed_nslots;
     sp.qthr = qthr; sp.fail = (int *)h->ws_flag.p;
-    return launch_select(sp, s);
+    return launch_select(sp, s, &h->ws_tmp);
 }
 
 // queries [nq][dp] already on device (padded); writes sorted keys [nq][k] and/or D/I.

@@ -270,6 +270,24 @@ def test_statistical_seed_failure_is_caught_and_repaired(gpu_faiss, oracle, metr
     _assert_same(D2[-100:], I2[-100:], *oracle.flat_search(xb, xq2[-100:], k, metric))
 
 
+@pytest.mark.parametrize("flags", [8, 16, 0])
+def test_long_candidate_arrays_take_the_segment_pass(gpu_faiss, oracle, flags):
+    """Few queries against many rows: hundreds of chunks hand on their survivors, the per-query candidate arrays are
+    sized for more than 32768 keys and the final selection runs its segment pass first (flags=8: unseeded, arrays
+    really that long; 16: exact seed; 0: whatever the plan picks)."""
+    rng = np.random.default_rng(900 + flags)
+    nb, d, nq, k = 300_000, 32, 5, 100
+    xb = rng.standard_normal((nb, d), dtype=np.float32)
+    xq = rng.standard_normal((nq, d), dtype=np.float32)
+    for metric in (0, 1):
+        idx = gpu_faiss.IndexFlat(d, metric)
+        idx.set_tuning(0, 0, flags)
+        idx.add(xb)
+        D, I = idx.search(xq, k)
+        assert idx.last_scan()["nchunks"] * 125 > 32768
+        _assert_same(D, I, *oracle.flat_search(xb, xq, k, metric))
+
+
 def test_normalize_matches_oracle(gpu_faiss, oracle):
     rng = np.random.default_rng(11)
     for n, d in ((1000, 1024), (333, 100), (50, 37), (1, 1024), (129, 8)):
