@@ -142,6 +142,9 @@ int knn_hnsw_set_walk(knn_hnsw_handle h, int32_t expand, int32_t max_batch);
 int knn_hnsw_get_params(knn_hnsw_handle h, int32_t *M, int32_t *efSearch, int32_t *efConstruction,
                         int32_t *max_level, int64_t *entry_point);
 int knn_hnsw_add(knn_hnsw_handle h, const float *x_host, int64_t n);
+/* the same for rows already on the index's device ([n][d] contiguous): a graph over a database that
+ * never existed in host memory */
+int knn_hnsw_add_dev(knn_hnsw_handle h, const float *x_dev, int64_t n, void *stream);
 int knn_hnsw_search(knn_hnsw_handle h, const float *q_host, int64_t nq, int64_t k, float *D_host,
                     int64_t *I_host);
 int64_t knn_hnsw_ntotal(knn_hnsw_handle h);

@@ -244,6 +244,12 @@ class IndexHNSWFlat(Index):
         _lib.check(_lib.lib().knn_hnsw_search(self._h, x.ctypes.data, x.shape[0], k, D.ctypes.data, I.ctypes.data))
         return D, I
 
+    def add_dev(self, x):
+        """knn355 extra: rows from a float32 CUDA tensor [n, d] on the index's device (no host copy)."""
+        if not (x.is_cuda and x.is_contiguous() and x.dim() == 2 and x.shape[1] == self._d and x.element_size() == 4):
+            raise ValueError("add_dev: expected a contiguous float32 CUDA tensor [n, d]")
+        _lib.check(_lib.lib().knn_hnsw_add_dev(self._h, x.data_ptr(), x.shape[0], None))
+
     def set_walk(self, expand=0, max_batch=0):
         """knn355 extra: candidates expanded per walker per lock-step round / walkers per batch."""
         _lib.check(_lib.lib().knn_hnsw_set_walk(self._h, int(expand), int(max_batch)))
