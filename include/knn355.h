@@ -54,6 +54,11 @@ int knn_device_count(void);
 /* freed index storage and scratch buffers are kept in a per-device pool (<= 8 GiB) for the
  * next index; knn_trim() returns them to the driver and reports the bytes released */
 int64_t knn_trim(void);
+/* page-locked host memory (hipHostMalloc) for result arrays: a search result is downloaded into it
+ * by one DMA at PCIe line rate; into pageable memory the runtime stages the copy.  The faiss-shaped
+ * facade allocates large D / I arrays here (numpy arrays over a small pool).  NULL on failure. */
+void *knn_host_alloc(int64_t bytes);
+void knn_host_free(void *p);
 /* selects the device used by indexes created afterwards by this thread and
  * lazily creates its context (fork safe: nothing happens at load time;
  * cath/compare_seqvec_layer.py:58-64 calls search from forked workers) */
@@ -237,8 +242,10 @@ int32_t knn_scan_times(knn_handle h, float *out_ms, int32_t max_n);
 /* how the last search on this handle was seeded: seed_stride = 0 (no seed sample) or the
  * stride of the sample searched first; stat_rank = 0 (the sample's k-th score, a proven bound)
  * or j (statistical seed: the sample's j-th score, result verified); stat_redo = searches
- * repeated so far because a statistical threshold failed its verification */
-int knn_last_seed_info(knn_handle h, int32_t *seed_stride, int32_t *stat_rank, int64_t *stat_redo);
+ * repeated so far because a statistical threshold failed its verification; sample_rows =
+ * rows scanned by the sample pass (the main scan kernel skips them) */
+int knn_last_seed_info(knn_handle h, int32_t *seed_stride, int32_t *stat_rank, int64_t *stat_redo,
+                       int64_t *sample_rows);
 /* force a scan configuration: query_tile in {0(auto),32,64,128}; nchunks 0=auto;
  * flags: 8 = no seed sample, 16 = force the exact seed, 128 = force the statistical seed
  * (synchronous entry points only), 512 = never use the statistical seed */

@@ -1342,6 +1342,7 @@ struct knn_index_s {
     static const int MAX_LEVELS = 8;
     LevelBufs ws_level[MAX_LEVELS]; // per seed-recursion level
     int last_seed_stride = 0, last_seed_stat = 0;
+    int64_t last_sample_rows = 0; // rows the seed sample took out of the main pass of the last search
     int64_t stat_redo = 0;        // searches repeated because the statistical threshold was too tight
     int *flag_host = nullptr;     // pinned: [slot] copy of ws_flag behind each batch of a host search
     // tuning + introspection
@@ -1974,6 +1975,7 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
         h->last_kernel = pl.name; h->last_qt = pl.qt; h->last_dt = pl.dt; h->last_chunks = pl.nchunks; h->last_grid = pl.grid;
         h->last_seed_stride = sstride;
         h->last_seed_stat = seed_stat ? seed_j : 0;
+        h->last_sample_rows = sstride ? view_rows(nb, sstride, p.vshift) : 0;
     }
     // final selection: every query's candidates (seed list + the chunks' survivors) -> sorted top-k
     SelectParams sp = {};
@@ -2375,9 +2377,28 @@ extern "C" int32_t knn_scan_times(knn_handle h, float *out_ms, int32_t max_n)
     return (int32_t)n;
 }
 
-extern "C" int knn_last_seed_info(knn_handle h, int32_t *seed_stride, int32_t *stat_rank, int64_t *stat_redo)
+// Page-locked host memory for result arrays: the download of a search result into it is one DMA at PCIe
+// line rate (into pageable memory the runtime stages through its own pinned buffer at a third of that).
+extern "C" void *knn_host_alloc(int64_t bytes)
+{
+    if (bytes <= 0) return nullptr;
+    if (ensure_device(g_device)) return nullptr;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, (size_t)bytes, hipHostMallocPortable) != hipSuccess) {
+        set_err(KNN_ERR_HIP, "host_alloc: hipHostMalloc failed");
+        return nullptr;
+    }
+    return p;
+}
+extern "C" void knn_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
+extern "C" int knn_last_seed_info(knn_handle h, int32_t *seed_stride, int32_t *stat_rank, int64_t *stat_redo, int64_t *sample_rows)
 {
     if (!h) return set_err(KNN_ERR_INVALID, "null handle");
+    if (sample_rows) *sample_rows = h->last_sample_rows;
     if (seed_stride) *seed_stride = h->last_seed_stride;
     if (stat_rank) *stat_rank = h->last_seed_stat;
     if (stat_redo) *stat_redo = h->stat_redo;

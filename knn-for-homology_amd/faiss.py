@@ -93,8 +93,8 @@ class IndexFlat(Index):
         k = int(k)
         if k < 1:
             raise AssertionError("k must be positive")
-        D = np.empty((x.shape[0], k), np.float32)
-        I = np.empty((x.shape[0], k), np.int64)
+        D = _lib.result_array((x.shape[0], k), np.float32)
+        I = _lib.result_array((x.shape[0], k), np.int64)
         _lib.check(_lib.lib().knn_flat_search(self._h, x.ctypes.data, x.shape[0], k, D.ctypes.data, I.ctypes.data))
         return D, I
 
@@ -118,8 +118,8 @@ class IndexFlat(Index):
         if k < 1:
             raise AssertionError("k must be positive")
         nrows = self.ntotal - row0 if nrows is None else int(nrows)
-        D = np.empty((nrows, k), np.float32)
-        I = np.empty((nrows, k), np.int64)
+        D = _lib.result_array((nrows, k), np.float32)
+        I = _lib.result_array((nrows, k), np.int64)
         _lib.check(_lib.lib().knn_flat_search_self(self._h, int(row0), nrows, k, D.ctypes.data, I.ctypes.data))
         return D, I
 
@@ -151,10 +151,11 @@ class IndexFlat(Index):
 
     def last_seed(self):
         """{"stride": seed-sample stride of the last search (0: none), "stat_rank": j of a statistical seed
-        (0: exact bound), "stat_redo": searches repeated because a statistical threshold failed verification}"""
-        st, j, redo = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64()
-        _lib.check(_lib.lib().knn_last_seed_info(self._h, ctypes.byref(st), ctypes.byref(j), ctypes.byref(redo)))
-        return {"stride": st.value, "stat_rank": j.value, "stat_redo": redo.value}
+        (0: exact bound), "stat_redo": searches repeated because a statistical threshold failed verification,
+        "sample_rows": rows the sample pass scanned instead of the main scan kernel}"""
+        st, j, redo, rows = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(_lib.lib().knn_last_seed_info(self._h, ctypes.byref(st), ctypes.byref(j), ctypes.byref(redo), ctypes.byref(rows)))
+        return {"stride": st.value, "stat_rank": j.value, "stat_redo": redo.value, "sample_rows": rows.value}
 
     def __del__(self):
         h = getattr(self, "_h", None)

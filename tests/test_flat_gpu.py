@@ -288,6 +288,37 @@ def test_long_candidate_arrays_take_the_segment_pass(gpu_faiss, oracle, flags):
         _assert_same(D, I, *oracle.flat_search(xb, xq, k, metric))
 
 
+def test_large_results_live_in_page_locked_memory(gpu_faiss, oracle):
+    """(D, I) of >= 4 MB are numpy arrays over pooled hipHostMalloc blocks (one DMA at PCIe line rate instead of a
+    staged copy): ordinary writable arrays that outlive their index, whose block goes back to the pool with the last view."""
+    import gc
+    from knn_for_homology_amd import _lib
+    rng = np.random.default_rng(3)
+    xb = rng.standard_normal((3000, 32), dtype=np.float32)
+    xq = rng.standard_normal((6000, 32), dtype=np.float32)
+    idx = gpu_faiss.IndexFlat(32, 1)
+    idx.add(xb)
+    D, I = idx.search(xq, 200)          # 4.8 MB + 9.6 MB
+    assert not D.flags.owndata and not I.flags.owndata and D.flags.writeable and D.flags.c_contiguous
+    del idx
+    gc.collect()
+    Do, Io = oracle.flat_search(xb, xq, 200, 1)
+    _assert_same(D, I, Do, Io)
+    view = I[:, 1:]                      # what cath.search.search hands out
+    del I
+    gc.collect()
+    assert np.array_equal(view, Io[:, 1:])
+    D[0, 0] = 7.0                        # writable (pfam/proteins.py:85-122 swaps entries in place)
+    cls = 1 << (D.nbytes - 1).bit_length()
+    before = len(_lib._pinned_free.get(cls, []))
+    del D
+    gc.collect()
+    assert len(_lib._pinned_free.get(cls, [])) == before + 1
+    small = gpu_faiss.IndexFlat(32, 1)
+    small.add(xb)
+    assert small.search(xq[:10], 5)[0].flags.owndata  # small results stay plain numpy
+
+
 def test_normalize_matches_oracle(gpu_faiss, oracle):
     rng = np.random.default_rng(11)
     for n, d in ((1000, 1024), (333, 100), (50, 37), (1, 1024), (129, 8)):

@@ -20,6 +20,7 @@ dev = torch.device("cuda:0")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 nq = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 max_batch = int(sys.argv[3]) if len(sys.argv) > 3 else 16384
+efc = int(sys.argv[4]) if len(sys.argv) > 4 else 40
 d, k, M = 1024, 100, 32
 ncent = max(2000, n // 100)  # SURVEY 8(d) S-pfam: ~100 rows per centre
 g = torch.Generator(device=dev)
@@ -27,6 +28,7 @@ g.manual_seed(21)
 cent = torch.randn((ncent, d), generator=g, device=dev)
 idx = faiss.IndexHNSWFlat(d, M, faiss.METRIC_INNER_PRODUCT)
 idx.set_walk(0, max_batch)
+idx.hnsw.efConstruction = efc
 flat = faiss.IndexFlat(d, faiss.METRIC_INNER_PRODUCT)
 _lib.check(L.knn_flat_reserve(flat._h, n))
 _lib.check(L.knn_flat_reserve(L.knn_hnsw_storage(idx._h), n))
@@ -56,7 +58,7 @@ t_flat = time.perf_counter() - t0
 idx.hnsw.efSearch = 256
 idx.search(q[:256], k)  # uploads the level-0 lists
 res = {}
-for efs in (64, 128, 256):
+for efs in (128, 256, 512, 1024):
     idx.hnsw.efSearch = efs
     ts = []
     for _ in range(3):
@@ -67,6 +69,6 @@ for efs in (64, 128, 256):
     rec = float(np.mean([len(np.intersect1d(a[a >= 0], b)) for a, b in zip(I, It)])) / k
     res[efs] = {"queries_per_s": nq / t, "recall_at_100": rec}
     print(f"  efSearch={efs}: {nq / t:.0f} q/s, recall@100 {rec:.4f}", flush=True)
-out = {"rows": n, "d": d, "M": M, "k": k, "nq": nq, "centres": ncent, "build_s": t_build, "build_rows_per_s": n / t_build,
+out = {"max_batch": max_batch, "efConstruction": efc, "rows": n, "d": d, "M": M, "k": k, "nq": nq, "centres": ncent, "build_s": t_build, "build_rows_per_s": n / t_build,
        "flat_queries_per_s": nq / t_flat, "hnsw": res, "stats": idx.stats()}
 print(json.dumps(out))
