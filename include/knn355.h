@@ -144,6 +144,10 @@ int knn_hnsw_set_ef(knn_hnsw_handle h, int32_t efSearch, int32_t efConstruction)
 /* walk tuning (not in faiss): candidates expanded per walker per lock-step round (default 8;
  * 1 = strict best-first) and walkers per batch (default 4096); values <= 0 keep the setting */
 int knn_hnsw_set_walk(knn_hnsw_handle h, int32_t expand, int32_t max_batch);
+/* where the level-0 walk of a search starts (not in faiss): coarse_entries > 0 -- at the coarse_entries
+ * nearest nodes above level 0, found by an exact scan of those rows on the flat kernel (default 4);
+ * 0 -- where FAISS's greedy descent through the upper levels ends */
+int knn_hnsw_set_entry(knn_hnsw_handle h, int32_t coarse_entries);
 int knn_hnsw_get_params(knn_hnsw_handle h, int32_t *M, int32_t *efSearch, int32_t *efConstruction,
                         int32_t *max_level, int64_t *entry_point);
 int knn_hnsw_add(knn_hnsw_handle h, const float *x_host, int64_t n);

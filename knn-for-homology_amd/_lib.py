@@ -61,6 +61,7 @@ def _declare(L):
         "knn_hnsw_create": (c_int32, [c_int32, c_int32, c_int32, POINTER(H)]),
         "knn_hnsw_set_ef": (c_int32, [H, c_int32, c_int32]),
         "knn_hnsw_set_walk": (c_int32, [H, c_int32, c_int32]),
+        "knn_hnsw_set_entry": (c_int32, [H, c_int32]),
         "knn_hnsw_get_params": (c_int32, [H, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int64)]),
         "knn_hnsw_add": (c_int32, [H, c_void_p, c_int64]),
         "knn_hnsw_add_dev": (c_int32, [H, c_void_p, c_int64, c_void_p]),

@@ -251,6 +251,10 @@ class IndexHNSWFlat(Index):
             raise ValueError("add_dev: expected a contiguous float32 CUDA tensor [n, d]")
         _lib.check(_lib.lib().knn_hnsw_add_dev(self._h, x.data_ptr(), x.shape[0], None))
 
+    def set_entry(self, coarse_entries=4):
+        """knn355 extra: level-0 entry points per query from an exact scan of the nodes above level 0 (0: FAISS's greedy descent)."""
+        _lib.check(_lib.lib().knn_hnsw_set_entry(self._h, int(coarse_entries)))
+
     def set_walk(self, expand=0, max_batch=0):
         """knn355 extra: candidates expanded per walker per lock-step round / walkers per batch."""
         _lib.check(_lib.lib().knn_hnsw_set_walk(self._h, int(expand), int(max_batch)))

@@ -77,6 +77,34 @@ def test_recall_and_distance_bits(gpu_faiss, metric):
     assert _recall(I128, It[:, :10]) >= _recall(I16, It[:, :10]) >= 0.8
 
 
+@pytest.mark.parametrize("metric", [0, 1])
+def test_entry_modes_and_host_walk_agree_in_quality(gpu_faiss, metric, monkeypatch):
+    """Three ways to walk the same graph: coarse exact entry scan + device beam (default), greedy descent + device beam
+    (set_entry(0)), and the host beam of round 1.  All return flat-exact distances for the rows they find and reach the
+    same recall within two points; the default must not be the worst."""
+    n, d, nq, k = 30000, 128, 800, 50
+    x = _clustered(n, d, 300, 77)
+    gpu_faiss.normalize_L2(x)
+    flat = gpu_faiss.IndexFlat(d, metric)
+    flat.add(x)
+    Dt, It = flat.search(x[:nq], k)
+    idx = gpu_faiss.IndexHNSWFlat(d, 32, metric)
+    idx.add(x)
+    idx.hnsw.efSearch = 128
+    rec = {}
+    for name, entries in (("coarse", 4), ("descent", 0)):
+        idx.set_entry(entries)
+        D, I = idx.search(x[:nq], k)
+        rec[name] = _recall(I, It)
+        ref = [dict(zip(It[r].tolist(), Dt[r].view(np.uint32).tolist())) for r in range(50)]
+        for r in range(50):
+            for j, v in zip(I[r].tolist(), D[r].view(np.uint32).tolist()):
+                if j in ref[r]:
+                    assert ref[r][j] == v
+        assert (np.diff(D, axis=1) <= 0).all() if metric == 0 else (np.diff(D, axis=1) >= 0).all()
+    assert rec["coarse"] >= 0.95 and rec["coarse"] >= rec["descent"] - 0.02, rec
+
+
 def test_graph_invariants_and_determinism(gpu_faiss):
     n, d, M = 6000, 64, 16
     x = _clustered(n, d, 50, 5)
