@@ -455,6 +455,7 @@ struct ScanParams {
     int vshift;        // log2 of the view's block size (3: blocks of 8 rows, 0: single rows)
     int skip_mask;     // >= 0: rows whose block b has (b & skip_mask) == 0 belong to the seed sample, skip them
     int kslot;         // most keys a chunk hands on per query: k + k/4
+    int stagger;       // start delay (units of 64 cycles) of workgroups in odd wave slots, see flat_scan_kernel
 };
 
 // Views: view row r of a launch with stride row_mul and block size B = 1 << vshift is database row
@@ -667,6 +668,16 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
     L.k = p.k;
     L.kslot = p.kslot;
     L.init(tid, QT);
+    // Two workgroups share each CU, one wave of each per SIMD.  Dispatched together and running the same
+    // program at the same speed (the matrix pipe is shared fairly), they would stay in lock step for the
+    // whole launch: both waves of a SIMD reach their K-step barrier -- and the LDS read after it -- at the
+    // same time, and the pipe idles.  The workgroup that got the odd wave slots starts half a K step late
+    // instead, so that one wave's barrier falls into the middle of the other's MFMA stream.
+    if (p.stagger > 0) {
+        const uint32_t slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4); // HW_REG_HW_ID.WAVE_ID
+        if (slot & 1u)
+            for (int i = 0; i < p.stagger; i++) __builtin_amdgcn_s_sleep(64);
+    }
     __syncthreads();
     // per-lane staging bookkeeping: instruction ii covers combined rows 8*ii..8*ii+7
     const float *srcp[NI];
@@ -1875,7 +1886,7 @@ struct SearchOut {
 // Exact top-k of the block-strided view (view_row) with stride row_mul / block shift vshift for
 // queries [nq][dp] on the device.  allow_stat: the caller checks h->ws_flag afterwards.
 static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int64_t nq, int k, uint32_t id_base, int row_mul,
-                       int vshift, int level, const SearchOut &out, bool allow_stat, hipStream_t s)
+                       int vshift, int level, const SearchOut &out, bool allow_stat, hipStream_t s, int *reset_flag = nullptr)
 {
     const int64_t nb = view_rows(h->ntotal, row_mul, vshift);
     ScanPlan pl;
@@ -1934,12 +1945,13 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
         so.keys = qlist; so.keys_stride = qcap; so.keys_fill = 0;
         so.seed_cnt = qcnt; so.seed_gthr = gthr; so.seed_qthr = qthr; so.seed_j = seed_j; so.seed_stat = seed_stat;
         so.seed_nslots = (int64_t)nslots;
-        rc = search_view(h, q_dev, xn, nq, k, id_base, row_mul * sstride, svshift, level + 1, so, false, s);
+        rc = search_view(h, q_dev, xn, nq, k, id_base, row_mul * sstride, svshift, level + 1, so, false, s, reset_flag);
         if (rc) return rc;
     } else {
         const int64_t nn = std::max<int64_t>((int64_t)nslots, nq);
+        // (the first launch of a search: it also clears the verification flag)
         hipLaunchKernelGGL(init_level_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, s, gthr, (int64_t)nslots, qcnt, qthr, nq,
-                           (int *)nullptr);
+                           reset_flag);
         HIP_TRY(hipGetLastError());
     }
     if (h->ws_lists.ensure((size_t)pl.grid * pl.qt * pl.cap * 8)) return set_err(KNN_ERR_HIP, "search: out of device memory (candidate lists)");
@@ -1954,6 +1966,10 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     p.vshift = sstride ? svshift : vshift;
     p.skip_mask = sstride ? sstride - 1 : -1;
     p.kslot = kslot;
+    {
+        static const int stagger_env = getenv("KNN355_STAGGER") ? atoi(getenv("KNN355_STAGGER")) : 0;
+        p.stagger = stagger_env;
+    }
     const bool top = level == 0;
     if (top) {
         const int slot = (int)(h->nlaunches % knn_index_s::RING);
@@ -2005,11 +2021,10 @@ static int search_keys_impl(knn_index_s *h, const float *q_dev, int64_t nq, int 
         xn = (const float *)h->ws_qn.p;
     }
     if (h->ws_flag.ensure(64)) return set_err(KNN_ERR_HIP, "search: out of device memory");
-    HIP_TRY(hipMemsetAsync(h->ws_flag.p, 0, 4, s));
     SearchOut out;
     out.keys = keys_out; out.keys_stride = k; out.keys_fill = 0;
     out.D = D_out; out.I = I_out;
-    return search_view(h, q_dev, xn, nq, k, id_base, 1, 3, 0, out, allow_stat, s);
+    return search_view(h, q_dev, xn, nq, k, id_base, 1, 3, 0, out, allow_stat, s, (int *)h->ws_flag.p);
 }
 
 static int check_search_args(knn_index_s *h, const void *q, int64_t nq, int64_t k, const void *D, const void *I)
