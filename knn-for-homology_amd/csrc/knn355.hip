@@ -455,7 +455,6 @@ struct ScanParams {
     int vshift;        // log2 of the view's block size (3: blocks of 8 rows, 0: single rows)
     int skip_mask;     // >= 0: rows whose block b has (b & skip_mask) == 0 belong to the seed sample, skip them
     int kslot;         // most keys a chunk hands on per query: k + k/4
-    int stagger;       // start delay (units of 64 cycles) of workgroups in odd wave slots, see flat_scan_kernel
 };
 
 // Views: view row r of a launch with stride row_mul and block size B = 1 << vshift is database row
@@ -668,16 +667,6 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
     L.k = p.k;
     L.kslot = p.kslot;
     L.init(tid, QT);
-    // Two workgroups share each CU, one wave of each per SIMD.  Dispatched together and running the same
-    // program at the same speed (the matrix pipe is shared fairly), they would stay in lock step for the
-    // whole launch: both waves of a SIMD reach their K-step barrier -- and the LDS read after it -- at the
-    // same time, and the pipe idles.  The workgroup that got the odd wave slots starts half a K step late
-    // instead, so that one wave's barrier falls into the middle of the other's MFMA stream.
-    if (p.stagger > 0) {
-        const uint32_t slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4); // HW_REG_HW_ID.WAVE_ID
-        if (slot & 1u)
-            for (int i = 0; i < p.stagger; i++) __builtin_amdgcn_s_sleep(64);
-    }
     __syncthreads();
     // per-lane staging bookkeeping: instruction ii covers combined rows 8*ii..8*ii+7
     const float *srcp[NI];
@@ -1966,10 +1955,6 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     p.vshift = sstride ? svshift : vshift;
     p.skip_mask = sstride ? sstride - 1 : -1;
     p.kslot = kslot;
-    {
-        static const int stagger_env = getenv("KNN355_STAGGER") ? atoi(getenv("KNN355_STAGGER")) : 0;
-        p.stagger = stagger_env;
-    }
     const bool top = level == 0;
     if (top) {
         const int slot = (int)(h->nlaunches % knn_index_s::RING);

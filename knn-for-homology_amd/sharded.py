@@ -59,7 +59,12 @@ class HipShardBackend:
     def next_lane(self):
         """(index handle object, torch stream) of the lane whose turn it is."""
         if self._lanes is None:
-            self._lanes = [(self.index, torch.cuda.Stream(self.device)), (self.index.view(), torch.cuda.Stream(self.device))]
+            # different priorities = different hardware queues: two streams of one priority can land on the same
+            # queue (the runtime multiplexes its streams over a few), and then the lanes run strictly one after
+            # the other -- measured: no overlap at all, two lanes = one lane
+            prio = [int(v) for v in os.environ.get("KNN355_LANE_PRIORITIES", "0,-1").split(",")]
+            self._lanes = [(self.index, torch.cuda.Stream(self.device, priority=prio[0])),
+                           (self.index.view(), torch.cuda.Stream(self.device, priority=prio[1]))]
         lane = self._lanes[self._turn]
         self._turn ^= 1
         return lane

@@ -32,7 +32,7 @@ for nb in sizes:
         idx.add_dev(x)
         del x
     idx.backend.next_lane(); idx.backend.next_lane()
-    for nch in (0, 768, 1024, 1536):
+    for nch in ([int(a) for a in os.environ.get('LANE_CHUNKS','').split(',') if a] or (0, 768, 1024, 1536)):
         for lane_index, _ in idx.backend._lanes:
             lane_index.set_tuning(0, nch, 0)
         for mode in ("two lanes", "one lane"):
