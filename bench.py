@@ -243,7 +243,7 @@ def run(args):
         tfile = ROOT / "profiles" / "pmc_traffic.json"
         if tfile.exists():
             try:
-                rec = json.loads(tfile.read_text()).get(info["kernel"], {})
+                rec = json.loads(tfile.read_text()).get(info["kernel"] + "_ip", {})
                 # the counters were collected on the default workload: only quote them for it
                 if rec.get("algorithmic_bytes_per_launch") == alg_bytes:
                     traffic = rec.get("hbm_bytes_per_launch")

@@ -1904,7 +1904,10 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
             make_plan(h, nb, nq, k, false, un);
             const double unseeded = (double)un.nchunks * k * (1.0 + log(std::max(1.0, (double)un.chunk_rows / k)));
             const double seeded = (double)j * (double)nb / (double)S;
-            if (force || seeded <= 0.5 * unseeded) {
+            // ... and if those candidates are a sizeable share of all scores (Pfam-sized k = 100: 5 % of the scores go
+            // through the lists, an unseeded scan loses ~5 % to them and the sample pass would cost 3 %: not worth it;
+            // k = 1000: 17 %, CATH-sized k = 301: 50 %)
+            if (force || (seeded <= 0.5 * unseeded && unseeded >= 0.08 * (double)nb)) {
                 sstride = st;
                 seed_j = j;
                 seed_stat = 1;
@@ -1934,7 +1937,10 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
         so.keys = qlist; so.keys_stride = qcap; so.keys_fill = 0;
         so.seed_cnt = qcnt; so.seed_gthr = gthr; so.seed_qthr = qthr; so.seed_j = seed_j; so.seed_stat = seed_stat;
         so.seed_nslots = (int64_t)nslots;
-        rc = search_view(h, q_dev, xn, nq, k, id_base, row_mul * sstride, svshift, level + 1, so, false, s, reset_flag);
+        // a statistical seed needs the sample's best ~1.25 j rows only (its bound has rank <= 1.25 j, and only rows that
+        // beat the bound are handed on): the sample is searched with that k, not the caller's
+        const int k_sample = seed_stat ? std::min(k, seed_j + std::max(seed_j >> 2, 8) + 8) : k;
+        rc = search_view(h, q_dev, xn, nq, k_sample, id_base, row_mul * sstride, svshift, level + 1, so, false, s, reset_flag);
         if (rc) return rc;
     } else {
         const int64_t nn = std::max<int64_t>((int64_t)nslots, nq);

@@ -105,6 +105,27 @@ def test_entry_modes_and_host_walk_agree_in_quality(gpu_faiss, metric, monkeypat
     assert rec["coarse"] >= 0.95 and rec["coarse"] >= rec["descent"] - 0.02, rec
 
 
+def test_add_dev_builds_the_same_graph(gpu_faiss):
+    """knn_hnsw_add_dev (rows already on the device, no host copy of the database) links the same graph as add()."""
+    import torch
+    n, d = 9000, 64
+    x = _clustered(n, d, 90, 12)
+    a = gpu_faiss.IndexHNSWFlat(d, 16, 0)
+    a.add(x)
+    b = gpu_faiss.IndexHNSWFlat(d, 16, 0)
+    xd = torch.from_numpy(x).to("cuda:0")
+    b.add_dev(xd[:5000].contiguous())
+    b.add_dev(xd[5000:].contiguous())
+    c = gpu_faiss.IndexHNSWFlat(d, 16, 0)
+    c.add(x[:5000])
+    c.add(x[5000:])
+    assert b.ntotal == n and np.array_equal(b.graph()[2], c.graph()[2]), "same rows in the same two calls: same graph"
+    assert np.array_equal(b.reconstruct_n(0, n), x)
+    Da, Ia = a.search(x[:200], 10)
+    Db, Ib = b.search(x[:200], 10)
+    assert _recall(Ib, Ia) > 0.9  # (one call vs two calls batch the insertions differently: close, not identical)
+
+
 def test_graph_invariants_and_determinism(gpu_faiss):
     n, d, M = 6000, 64, 16
     x = _clustered(n, d, 50, 5)

@@ -55,7 +55,8 @@ def dev_search(idx, q, k, reps=5):
         scans.append(idx.last_scan()["ms"])
     info = idx.last_scan()
     wall, scan = float(np.median(walls[1:])), float(np.median(scans[1:]))
-    nb, d = idx.ntotal, idx.d
+    seed = idx.last_seed()
+    nb, d = idx.ntotal - seed["sample_rows"], idx.d  # rows the timed scan launch covers (a seed sample has its own small launch)
     passes = (nq + info["query_tile"] - 1) // info["query_tile"]
     flops = 2.0 * nq * nb * d
     byts = passes * nb * d * 4 + nq * d * 4 + nq * k * 12

@@ -25,16 +25,12 @@ if bench_json.exists():
 
 
 def short(name):
+    # flat_scan_kernel<WM, WN, TM, TN, L2, NTDB>: a seed sample's pass is a small launch of the same instantiation;
+    # the metric is part of the name (the bench's main config is inner product, its batch config L2)
     if "flat_scan_kernel<" in name:
         targs = name[name.index("flat_scan_kernel<") + len("flat_scan_kernel<"):].split(">")[0].split(", ")
-        if len(targs) > 6 and targs[6] == "true":  # <WM, WN, TM, TN, L2, STG, SAMPLE, NTDB>
-            return "flat_scan_sample_pass"
-    if "flat_scan_kernel<4, 1, 2, 1" in name:
-        return "flat_scan_q32_d256"
-    if "flat_scan_kernel<2, 2, 2, 1" in name:
-        return "flat_scan_q64_d128"
-    if "flat_scan_kernel<2, 2, 2, 2" in name:
-        return "flat_scan_q128_d128"
+        tile = {"4, 1, 2, 1": "flat_scan_q32_d256", "2, 2, 2, 1": "flat_scan_q64_d128", "2, 2, 2, 2": "flat_scan_q128_d128"}[", ".join(targs[:4])]
+        return tile + ("_l2" if targs[4] == "true" else "_ip")
     return name.split("(")[0].replace("void ", "")[:60]
 
 
@@ -58,7 +54,7 @@ for kname in sorted(set(fetch) | set(write)):
     wmax = max(w) if w else 0.0
     hbm = (2.0 * fmax + wmax) * 1024.0
     rows.append((kname, len(f), fmax, wmax, hbm))
-    if kname.startswith("flat_scan") or kname.startswith("merge_select"):
+    if kname.startswith("flat_scan") or kname.startswith("select_topk"):
         traffic[kname] = {"hbm_bytes_per_launch": hbm, "fetch_size_kib_raw": fmax, "write_size_kib": wmax,
                           "note": "FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, largest launch"}
 with open(out / f"{tag}_pmc_hbm_traffic.csv", "w") as fh:
@@ -68,12 +64,22 @@ with open(out / f"{tag}_pmc_hbm_traffic.csv", "w") as fh:
 if bench_json.exists():
     try:
         b = json.loads(bench_json.read_text().strip().splitlines()[-1])
-        kern = b["roofline"]["kernel"]
+        kern = b["roofline"]["kernel"] + "_ip"
         if kern in traffic:
             traffic[kern]["algorithmic_bytes_per_launch"] = b["roofline"]["algorithmic_bytes_per_launch"]
             traffic[kern]["workload"] = b["config"]["workload"]
     except Exception as e:  # pragma: no cover
         print("could not attach workload to traffic:", e)
+    try:
+        bk = b["batch"]
+        kern = bk["kernel"] + "_l2"
+        if kern in traffic:
+            n = 14433
+            traffic[kern]["workload"] = bk["workload"]
+            traffic[kern]["result_bytes"] = n * 301 * 12
+            traffic[kern]["database_bytes"] = n * 1024 * 4
+    except Exception as e:  # pragma: no cover
+        print("could not attach the batch workload:", e)
 (out / "pmc_traffic.json").write_text(json.dumps(traffic, indent=1))
 print(open(out / f"{tag}_bench_kernel_stats.csv").read()[:1500])
 print(json.dumps(traffic, indent=1))
