@@ -132,6 +132,22 @@ int knn_reset(knn_handle h);
 int knn_flat_reconstruct(knn_handle h, int64_t i0, int64_t n, float *out_host);
 void knn_free(knn_handle h);
 
+/* ---- several GPUs without torch: RCCL inside the library -------------------------
+ * The reference has no multi-device code; the north star asks for a database
+ * row-sharded over the GPUs of a node with one all-gather of the per-shard top-k.  One process
+ * per GPU: rank 0 makes a unique id and hands it to the other ranks (a file, MPI, a socket --
+ * the caller's business), every rank creates its communicator, and knn_sharded_search_dev runs
+ * local scan -> ncclAllGather of the [nq][k] packed keys -> selection on one stream; the result
+ * (global ids: id_base + local row) is the same on every rank and does not depend on the number
+ * of shards.  librccl is dlopen'ed on first use.  (Python callers can use torch.distributed
+ * instead: knn_for_homology_amd.sharded.) */
+typedef struct knn_comm_s *knn_comm;
+int knn_comm_unique_id(uint8_t *id128);
+int knn_comm_create(const uint8_t *id128, int32_t world, int32_t rank, int32_t device, knn_comm *out);
+void knn_comm_free(knn_comm c);
+int knn_sharded_search_dev(knn_handle h, knn_comm c, const float *q_dev, int64_t nq, int64_t k,
+                           uint32_t id_base, float *D_dev, int64_t *I_dev, void *stream);
+
 /* ---- faiss.IndexHNSWFlat(d, M, metric) ------------------------------------
  * pfam/proteins_search.py:27-31 (M = 42, inner product, hnsw.efSearch = 256),
  * .train (no-op) / .add :35-37, .search(x, 1000) :49.  The graph is built and walked

@@ -47,6 +47,10 @@ def _declare(L):
         "knn_flat_view": (c_int32, [H, POINTER(H)]),
         "knn_flat_search_keys_dev": (c_int32, [H, c_void_p, c_int64, c_int64, c_uint32, c_void_p, c_void_p]),
         "knn_merge_keys_dev": (c_int32, [H, c_void_p, c_int32, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+        "knn_comm_unique_id": (c_int32, [c_void_p]),
+        "knn_comm_create": (c_int32, [c_void_p, c_int32, c_int32, c_int32, POINTER(H)]),
+        "knn_comm_free": (None, [H]),
+        "knn_sharded_search_dev": (c_int32, [H, H, c_void_p, c_int64, c_int64, c_uint32, c_void_p, c_void_p, c_void_p]),
         "knn_ntotal": (c_int64, [H]),
         "knn_dim": (c_int32, [H]),
         "knn_metric": (c_int32, [H]),

@@ -2505,6 +2505,133 @@ extern "C" int knn_gather_distances(knn_handle h, const float *q_host, int64_t n
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Several GPUs without torch: RCCL inside the library.  One process per GPU; rank 0 makes a
+// unique id (knn_comm_unique_id), the caller hands it to the other ranks by whatever means it
+// has (a file, MPI, a socket), every rank creates its communicator, and a sharded search is
+// local scan -> ncclAllGather of the [nq][k] packed keys -> selection, all on one stream.
+// librccl is opened on first use (dlopen): a process that shards through torch.distributed
+// instead (bench.py, sharded.py) never loads a second copy.
+// ---------------------------------------------------------------------------
+#include <dlfcn.h>
+struct Id128 { char b[128]; };
+struct RcclApi {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, /* ncclUniqueId by value: 128 bytes */ Id128, int) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+static RcclApi g_rccl;
+static std::mutex g_rccl_mu;
+static int rccl_load()
+{
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.lib) return 0;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *L = nullptr;
+    for (const char *nm : names)
+        if ((L = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!L) return set_err(KNN_ERR_UNSUPPORTED, std::string("comm: librccl not found (") + dlerror() + ")");
+    RcclApi a;
+    a.GetUniqueId = (int (*)(void *))dlsym(L, "ncclGetUniqueId");
+    a.CommInitRank = (int (*)(void **, int, Id128, int))dlsym(L, "ncclCommInitRank");
+    a.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(L, "ncclAllGather");
+    a.CommDestroy = (int (*)(void *))dlsym(L, "ncclCommDestroy");
+    a.GetErrorString = (const char *(*)(int))dlsym(L, "ncclGetErrorString");
+    if (!a.GetUniqueId || !a.CommInitRank || !a.AllGather || !a.CommDestroy || !a.GetErrorString)
+        return set_err(KNN_ERR_UNSUPPORTED, "comm: librccl lacks a required symbol");
+    a.lib = L;
+    g_rccl = a;
+    return 0;
+}
+#define RCCL_TRY(expr)                                                                                        \
+    do {                                                                                                      \
+        int r_ = (expr);                                                                                      \
+        if (r_ != 0) return set_err(KNN_ERR_HIP, std::string(#expr) + ": " + g_rccl.GetErrorString(r_));      \
+    } while (0)
+
+struct knn_comm_s {
+    void *comm = nullptr;
+    int world = 1, rank = 0, device = 0;
+    DevBuf keys, gathered;
+    std::mutex mu;
+};
+
+extern "C" int knn_comm_unique_id(uint8_t *id128)
+{
+    if (!id128) return set_err(KNN_ERR_INVALID, "comm_unique_id: null pointer");
+    int rc = rccl_load();
+    if (rc) return rc;
+    RCCL_TRY(g_rccl.GetUniqueId(id128));
+    return 0;
+}
+
+extern "C" int knn_comm_create(const uint8_t *id128, int32_t world, int32_t rank, int32_t device, knn_comm_s **out)
+{
+    if (!id128 || !out) return set_err(KNN_ERR_INVALID, "comm_create: null pointer");
+    if (world < 1 || rank < 0 || rank >= world) return set_err(KNN_ERR_INVALID, "comm_create: bad world / rank");
+    int rc = rccl_load();
+    if (rc) return rc;
+    rc = ensure_device(device);
+    if (rc) return rc;
+    knn_comm_s *c = new knn_comm_s();
+    c->world = world;
+    c->rank = rank;
+    c->device = device;
+    Id128 id;
+    memcpy(id.b, id128, 128);
+    int r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+    if (r != 0) {
+        delete c;
+        return set_err(KNN_ERR_HIP, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r));
+    }
+    *out = c;
+    return 0;
+}
+
+extern "C" void knn_comm_free(knn_comm_s *c)
+{
+    if (!c) return;
+    if (hipSetDevice(c->device) == hipSuccess) {
+        if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+        c->keys.release();
+        c->gathered.release();
+    }
+    delete c;
+}
+
+// h holds THIS rank's rows (global id of local row r = id_base + r); q_dev [nq][d] is the same on every rank;
+// D_dev / I_dev receive the global result on every rank.  Every rank must call with the same nq and k.
+extern "C" int knn_sharded_search_dev(knn_handle h, knn_comm_s *c, const float *q_dev, int64_t nq, int64_t k, uint32_t id_base,
+                                      float *D_dev, int64_t *I_dev, void *stream)
+{
+    if (!c) return set_err(KNN_ERR_INVALID, "sharded_search: null communicator");
+    int rc = check_search_args(h, q_dev, nq, k, D_dev, I_dev);
+    if (rc) return rc;
+    if (nq == 0) return 0;
+    if (h->device != c->device) return set_err(KNN_ERR_INVALID, "sharded_search: index and communicator live on different devices");
+    std::lock_guard<std::mutex> lc(c->mu);
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    const size_t nkeys = (size_t)nq * k;
+    if (c->keys.ensure(nkeys * 8) || c->gathered.ensure(nkeys * 8 * c->world)) return set_err(KNN_ERR_HIP, "sharded_search: out of device memory");
+    h->last_ms = -1.f;
+    rc = search_dev_impl(h, q_dev, nq, (int)k, nullptr, nullptr, (uint64_t *)c->keys.p, id_base, false, s);
+    if (rc) return rc;
+    RCCL_TRY(g_rccl.AllGather(c->keys.p, c->gathered.p, nkeys, /* ncclUint64 */ 5, c->comm, s));
+    SelectParams sp = {};
+    sp.in = (const uint64_t *)c->gathered.p; sp.lm_lists = c->world; sp.lm_k = (int)k;
+    sp.nq = nq; sp.k = (int)k; sp.metric = h->metric;
+    sp.D = D_dev; sp.I = I_dev;
+    rc = launch_select(sp, s);
+    if (rc) return rc;
+    if (!stream) HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
 #include "hnsw.inc"
 #include "lsh.inc"
 #include "eval.inc"

@@ -27,7 +27,7 @@ for case in range(ncases):
         nq = max(1, int(3e10 / (nb * d)))
     k = int(rng.choice([1, 2, 10, 11, 64, 100, 101, 301, 512, 1000, 1537, 2048]))
     metric = int(rng.integers(0, 2))
-    flags = int(rng.choice([0, 0, 0, 8, 16]))
+    flags = int(rng.choice([0, 0, 0, 8, 16, 128, 128]))
     qt = int(rng.choice([0, 0, 0, 32, 64, 128]))
     nch = int(rng.choice([0, 0, 0, 1, 3, 17]))
     kind = int(rng.integers(0, 6))

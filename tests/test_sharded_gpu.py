@@ -111,3 +111,36 @@ def test_submit_overlaps_two_lanes_and_matches_sync(gpu_faiss, oracle, monkeypat
             v.add(xb[:8])
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+
+
+def test_in_library_rccl_single_rank(gpu_faiss, oracle):
+    """The torch-free multi-GPU path of the C ABI (knn_comm_* + knn_sharded_search_dev: local scan -> ncclAllGather of
+    the packed keys -> selection, RCCL opened by the library itself).  One GPU here, so one rank: the collective is real
+    (a 1-rank communicator), the result must be the flat search's with the shard's id offset."""
+    import ctypes
+    import torch
+    from knn_for_homology_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(99)
+    nb, d, nq, k = 30000, 128, 40, 100
+    xb = rng.standard_normal((nb, d), dtype=np.float32)
+    xq = rng.standard_normal((nq, d), dtype=np.float32)
+    ident = (ctypes.c_uint8 * 128)()
+    _lib.check(L.knn_comm_unique_id(ident))
+    comm = ctypes.c_void_p()
+    _lib.check(L.knn_comm_create(ident, 1, 0, 0, ctypes.byref(comm)))
+    try:
+        dev = torch.device("cuda:0")
+        q = torch.from_numpy(xq).to(dev)
+        D = torch.empty((nq, k), device=dev, dtype=torch.float32)
+        I = torch.empty((nq, k), device=dev, dtype=torch.int64)
+        for metric in (0, 1):
+            idx = gpu_faiss.IndexFlat(d, metric)
+            idx.add(xb)
+            _lib.check(L.knn_sharded_search_dev(idx._h, comm, q.data_ptr(), nq, k, 5000, D.data_ptr(), I.data_ptr(), None))
+            Do, Io = oracle.flat_search(xb, xq, k, metric)
+            assert np.array_equal(I.cpu().numpy(), Io + 5000)
+            assert np.array_equal(D.cpu().numpy().view(np.uint32), Do.view(np.uint32))
+        assert L.knn_comm_create(ident, 2, 2, 0, ctypes.byref(ctypes.c_void_p())) != 0  # rank out of range
+    finally:
+        L.knn_comm_free(comm)
