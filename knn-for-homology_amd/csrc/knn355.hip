@@ -444,7 +444,7 @@ struct ScanParams {
     int k;
     int cap;           // candidate list capacity per (workgroup, query); power of two
     int nqtiles, nchunks;
-    int64_t chunk_rows; // multiple of the database tile
+    int tiles_base, tiles_rem; // chunk c walks tiles_base (+1 if c < tiles_rem) database tiles: a balanced split
     uint64_t *lists;   // [grid][QT][cap]
     uint32_t *gthr;    // [nqtiles*QT] shared running thresholds (order-mapped floats)
     uint64_t *qlist;   // [nq][qcap] compact candidate arrays: the chunks' survivors, appended as they finish
@@ -652,8 +652,8 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
     const int qtile = blockIdx.x % p.nqtiles;
     const int chunk = blockIdx.x / p.nqtiles;
     const int64_t q0 = (int64_t)qtile * QT;
-    const int64_t c_lo = (int64_t)chunk * p.chunk_rows;
-    const int64_t c_hi = min(p.nb, c_lo + p.chunk_rows);
+    const int64_t c_lo = ((int64_t)chunk * p.tiles_base + min(chunk, p.tiles_rem)) * DT;
+    const int64_t c_hi = min(p.nb, c_lo + (int64_t)(p.tiles_base + (chunk < p.tiles_rem ? 1 : 0)) * DT);
     const int KT = p.dp / 32;
     ListCtx L;
     L.s_thr = (float *)(smem + lds_main);
@@ -1755,6 +1755,7 @@ static int launch_select(SelectParams sp, hipStream_t s, DevBuf *tmp = nullptr)
 struct ScanPlan {
     int qt, dt, nqtiles, nchunks, cap, grid;
     int64_t chunk_rows;
+    int tiles_base, tiles_rem;
     size_t lds;
     const char *name;
 };
@@ -1814,8 +1815,13 @@ static void make_plan(const knn_index_s *h, int64_t nb, int64_t nq, int k, bool 
         want = best;
     }
     int64_t tiles_per = (ntiles + want - 1) / want;
-    pl.chunk_rows = tiles_per * pl.dt;
-    pl.nchunks = (int)((nb + pl.chunk_rows - 1) / pl.chunk_rows);
+    // balanced split: the first (ntiles mod nchunks) chunks walk one tile more.  (A uniform chunk length left the
+    // last chunk short -- 14433 rows in 9 chunks: 8 x 13 tiles + 9 -- and the two rounds of workgroups took 13 + 13
+    // tile times; 5 x 13 + 4 x 12 takes 13 + 12.)
+    pl.nchunks = (int)((ntiles + tiles_per - 1) / tiles_per);
+    pl.tiles_base = (int)(ntiles / pl.nchunks);
+    pl.tiles_rem = (int)(ntiles % pl.nchunks);
+    pl.chunk_rows = (int64_t)(pl.tiles_base + (pl.tiles_rem ? 1 : 0)) * pl.dt; // (the longest chunk)
     pl.grid = pl.nqtiles * pl.nchunks;
     pl.lds = std::max((size_t)2 * (pl.dt + pl.qt) * 128, (size_t)pl.cap * 8) + (size_t)qt * 12 + 16 + (size_t)pl.dt * 4;
 }
@@ -1902,7 +1908,10 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
             // worth it only if it removes most of the candidates an unseeded pass would collect
             ScanPlan un;
             make_plan(h, nb, nq, k, false, un);
-            const double unseeded = (double)un.nchunks * k * (1.0 + log(std::max(1.0, (double)un.chunk_rows / k)));
+            // (an unseeded chunk appends every score until its list first fills, cap - dt keys, whatever k is; then about
+            // k more per e-fold of rows)
+            const double warm = std::min<double>((double)un.cap - un.dt, (double)un.chunk_rows);
+            const double unseeded = (double)un.nchunks * std::max(warm, k * (1.0 + log(std::max(1.0, (double)un.chunk_rows / k))));
             const double seeded = (double)j * (double)nb / (double)S;
             // ... and if those candidates are a sizeable share of all scores (Pfam-sized k = 100: 5 % of the scores go
             // through the lists, an unseeded scan loses ~5 % to them and the sample pass would cost 3 %: not worth it;
@@ -1953,7 +1962,7 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     ScanParams p;
     p.xb = h->xb; p.yn = h->yn; p.xq = q_dev; p.xn = xn;
     p.nb = nb; p.nq = nq; p.dp = h->dp; p.k = k; p.cap = pl.cap;
-    p.nqtiles = pl.nqtiles; p.nchunks = pl.nchunks; p.chunk_rows = pl.chunk_rows;
+    p.nqtiles = pl.nqtiles; p.nchunks = pl.nchunks; p.tiles_base = pl.tiles_base; p.tiles_rem = pl.tiles_rem;
     p.lists = (uint64_t *)h->ws_lists.p; p.gthr = gthr;
     p.qlist = qlist; p.qcnt = qcnt; p.qcap = qcap;
     p.id_base = id_base;
