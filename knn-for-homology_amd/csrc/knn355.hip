@@ -1318,6 +1318,35 @@ struct LevelBufs {
     DevBuf qlist, qcnt, gthr, qthr;
 };
 
+// HIP streams are recycled: creating one costs a third of a millisecond, and the reference's scripts build a fresh
+// index per embedding file (cath/search.py:20-24).  A stream goes back to the pool fully drained.
+struct StreamPool {
+    std::mutex mu;
+    std::vector<std::pair<int, hipStream_t>> free_list;
+    hipStream_t take(int device)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t i = 0; i < free_list.size(); i++)
+                if (free_list[i].first == device) {
+                    hipStream_t s = free_list[i].second;
+                    free_list.erase(free_list.begin() + i);
+                    return s;
+                }
+        }
+        hipStream_t s = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        return s;
+    }
+    void give(int device, hipStream_t s)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (free_list.size() < 16) free_list.push_back({device, s});
+        else (void)hipStreamDestroy(s);
+    }
+};
+static StreamPool g_streams;
+
 struct knn_index_s {
     int d = 0, dp = 0, metric = 0, device = 0;
     int num_cus = 256;
@@ -1460,7 +1489,7 @@ extern "C" int knn_flat_create(int32_t d, int32_t metric, knn_handle *out)
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, g_device) == hipSuccess && cus > 0) h->num_cus = cus;
     }
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (!(h->stream = g_streams.take(h->device))) {
         delete h;
         return set_err(KNN_ERR_HIP, "flat_create: stream creation failed");
     }
@@ -1486,7 +1515,7 @@ extern "C" int knn_flat_view(knn_handle parent, knn_handle *out)
     h->yn = parent->yn;
     h->ntotal = parent->ntotal;
     h->cap_rows = parent->ntotal;
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (!(h->stream = g_streams.take(h->device))) {
         delete h;
         return set_err(KNN_ERR_HIP, "flat_view: stream creation failed");
     }
@@ -1534,7 +1563,7 @@ extern "C" void knn_free(knn_handle h)
             if (h->ring0[i]) (void)hipEventDestroy(h->ring0[i]);
             if (h->ring1[i]) (void)hipEventDestroy(h->ring1[i]);
         }
-        if (h->stream) (void)hipStreamDestroy(h->stream);
+        if (h->stream) g_streams.give(h->device, h->stream); // (synchronised above)
         if (h->flag_host) (void)hipHostFree(h->flag_host);
     }
     delete h;
@@ -2174,11 +2203,13 @@ static int host_search(knn_index_s *h, const float *q_host, int64_t self_row0, i
     // batch b-1 (pageable host memory: the copy blocks its caller) and this thread uploads the
     // queries of batch b+1, each on its own stream with its own staging buffers.
     int64_t QB = 16384;
-    // A single batch with a large result (CATH20-sized all-vs-all with 300 hits: 52 MB, as long on
-    // the wire as the scan takes) is split in up to four so that its download overlaps too; small
-    // results are not worth the extra launches and the extra streams of the pipelined path.
+    // A single batch with a large result (CATH20-sized all-vs-all with 300 hits: 52 MB, a millisecond on
+    // the wire) is split in two so that half of its download overlaps the scan; small results are not
+    // worth the extra launches and the extra streams of the pipelined path.
+    // (two halves: measured 5.1-5.2 ms for the CATH-sized k=301 search_self against 5.4 in one piece and 5.4 in four --
+    // every piece pays its own sample pass and selections)
     if (nq <= QB && (size_t)nq * k * 12 >= ((size_t)24 << 20) && nq >= 4096)
-        QB = std::max<int64_t>(2048, ((nq + 3) / 4 + 127) / 128 * 128);
+        QB = std::max<int64_t>(2048, ((nq + 1) / 2 + 127) / 128 * 128);
     const int64_t bq = std::min(nq, QB);
     const int64_t nbatches = (nq + QB - 1) / QB;
     DevBuf *qbuf[2] = {&h->ws_tmp2, &h->ws_tmp3}, *dbuf[2] = {&h->ws_D, &h->ws_D1}, *ibuf[2] = {&h->ws_I, &h->ws_I1};
