@@ -105,6 +105,27 @@ def test_entry_modes_and_host_walk_agree_in_quality(gpu_faiss, metric, monkeypat
     assert rec["coarse"] >= 0.95 and rec["coarse"] >= rec["descent"] - 0.02, rec
 
 
+def test_rows_wider_than_the_device_beam_use_the_host_walk(gpu_faiss):
+    """The device beam serves rows of up to 1024 floats; wider embeddings (ESM-1b: 1280) fall back to the host walk with
+    GPU distance batches -- same contract (flat-exact distances, -1 padding), recall against the flat search."""
+    n, d, nq, k = 4000, 1280, 200, 20
+    x = _clustered(n, d, 40, 3)
+    gpu_faiss.normalize_L2(x)
+    flat = gpu_faiss.IndexFlat(d, 0)
+    flat.add(x)
+    Dt, It = flat.search(x[:nq], k)
+    idx = gpu_faiss.IndexHNSWFlat(d, 16, 0)
+    idx.add(x)
+    idx.hnsw.efSearch = 128
+    D, I = idx.search(x[:nq], k)
+    assert _recall(I, It) >= 0.95 and (I[:, 0] == np.arange(nq)).mean() > 0.97
+    for r in range(20):
+        ref = dict(zip(It[r].tolist(), Dt[r].view(np.uint32).tolist()))
+        for j, v in zip(I[r].tolist(), D[r].view(np.uint32).tolist()):
+            if j in ref:
+                assert ref[j] == v
+
+
 def test_add_dev_builds_the_same_graph(gpu_faiss):
     """knn_hnsw_add_dev (rows already on the device, no host copy of the database) links the same graph as add()."""
     import torch
