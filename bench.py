@@ -420,6 +420,26 @@ def batch_config(dev, L, _lib, faiss):
     sm = float(np.median(scans))
     flops = 2.0 * n * n * d                               # the whole search
     flops_kernel = 2.0 * n * (n - seed["sample_rows"]) * d  # what the timed launch computes (the seed sample has its own launch)
+    # the same all-vs-all as a self-search of the index (what cath.search.search runs): only the score tiles on and
+    # above the diagonal are multiplied
+    ts, ss = [], []
+    for it in range(6):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _lib.check(L.knn_flat_search_self_dev(idx._h, k, D.data_ptr(), I.data_ptr()))
+        torch.cuda.synchronize()
+        if it >= 2:
+            ts.append(time.perf_counter() - t0)
+            ss.append(idx.last_scan()["ms"])
+    sinfo, sseed = idx.last_scan(), idx.last_seed()
+    st_, sm_ = float(np.median(ts)), float(np.median(ss))
+    tiles = (n + 127) // 128
+    flops_sym = 2.0 * (tiles * (tiles + 1) // 2) * 128 * 128 * d  # what the symmetric launch multiplies (whole tiles)
+    self_search = {"kernel": sinfo["kernel"], "ms": 1e3 * st_, "kernel_ms": sm_, "queries_per_s": n / st_, "seed": sseed,
+                   "roofline": {"bound": "mfma", "achieved": flops_sym / (sm_ * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                                "frac": flops_sym / (sm_ * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
+                                "note": "flops the launch executes (tiles on and above the diagonal), not 2*n*n*d"},
+                   "speedup_vs_plain_search": t / st_}
     # end to end as the reference times it (cath/search.py:42-46: copy + normalise + add + search), host numpy in/out
     from knn_for_homology_amd.cath.search import search as cath_search
     cath_search(xh, hits=300, metric=faiss.METRIC_L2)
@@ -436,6 +456,7 @@ def batch_config(dev, L, _lib, faiss):
                          "search_frac": flops / t / 1e12 / FP32_MFMA_PEAK_TF,
                          "note": "frac: the scan launch's own flops / its duration; search_frac: all 2*n*n*d flops / the whole "
                                  "device-resident search (sample pass, scan, final selection)"},
+            "self_search": self_search,
             "end_to_end": {"ms": 1e3 * float(np.median(e2e)), "queries_per_s": n / float(np.median(e2e)),
                            "what": "cath.search.search(numpy fp32[14433,1024], hits=300, L2): H2D 59 MB + add + search + D2H 52 MB"}}
 

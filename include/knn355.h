@@ -97,6 +97,11 @@ int knn_flat_search_dev(knn_handle h, const float *q_dev, int64_t nq, int64_t k,
  * normalise them here, and the caller's array stays untouched as in the reference). */
 int knn_flat_search_self(knn_handle h, int64_t row0, int64_t nrows, int64_t k, float *D_host,
                          int64_t *I_host);
+/* A self-search of the WHOLE index (row0 = 0, nrows = ntotal) multiplies only the score tiles on and
+ * above the diagonal: dot(x, y) = dot(y, x) bit for bit, so the tile of (query tile I, database tile J)
+ * also serves (query tile J, database tile I) -- half the matrix work, the same bits.
+ * knn_flat_search_self_dev: the same search with the results left on the device (synchronous). */
+int knn_flat_search_self_dev(knn_handle h, int64_t k, float *D_dev, int64_t *I_dev);
 int knn_flat_normalize_rows(knn_handle h);
 /* A second handle on the same device-resident rows with its own stream and scratch
  * memory (read-only: add/reset/reserve/normalize_rows fail on it; it sees the rows present
@@ -268,7 +273,8 @@ int knn_last_seed_info(knn_handle h, int32_t *seed_stride, int32_t *stat_rank, i
                        int64_t *sample_rows);
 /* force a scan configuration: query_tile in {0(auto),32,64,128}; nchunks 0=auto;
  * flags: 8 = no seed sample, 16 = force the exact seed, 128 = force the statistical seed
- * (synchronous entry points only), 512 = never use the statistical seed */
+ * (synchronous entry points only), 512 = never use the statistical seed, 1024 = never use the
+ * symmetric launch of a whole-index self-search */
 int knn_set_tuning(knn_handle h, int32_t query_tile, int32_t nchunks, int32_t flags);
 
 #ifdef __cplusplus

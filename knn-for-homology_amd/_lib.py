@@ -43,6 +43,7 @@ def _declare(L):
         "knn_flat_search": (c_int32, [H, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
         "knn_flat_search_dev": (c_int32, [H, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
         "knn_flat_search_self": (c_int32, [H, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
+        "knn_flat_search_self_dev": (c_int32, [H, c_int64, c_void_p, c_void_p]),
         "knn_flat_normalize_rows": (c_int32, [H]),
         "knn_flat_view": (c_int32, [H, POINTER(H)]),
         "knn_flat_search_keys_dev": (c_int32, [H, c_void_p, c_int64, c_int64, c_uint32, c_void_p, c_void_p]),

@@ -434,6 +434,12 @@ __device__ __forceinline__ int wave_select_dispatch_max(int R, LD load, int n, i
 // ---------------------------------------------------------------------------
 // scan kernel
 // ---------------------------------------------------------------------------
+// Symmetric all-vs-all (the queries ARE the database rows): workgroup w multiplies query tile qtile with the
+// database tiles [jt0, jt0 + jcount), all of them on or above the diagonal; see flat_scan_kernel<..., SYM>.
+struct SymItem {
+    int qtile, jt0, jcount;
+};
+
 struct ScanParams {
     const float *xb;   // [nb][dp] database rows, zero padded to dp
     const float *yn;   // [nb] squared norms (L2 only)
@@ -455,6 +461,8 @@ struct ScanParams {
     int vshift;        // log2 of the view's block size (3: blocks of 8 rows, 0: single rows)
     int skip_mask;     // >= 0: rows whose block b has (b & skip_mask) == 0 belong to the seed sample, skip them
     int kslot;         // most keys a chunk hands on per query: k + k/4
+    const struct SymItem *sym_items; // symmetric all-vs-all launch: the work of each workgroup (see flat_scan_kernel)
+    int *fail;         // symmetric launch: set when a candidate array overflows
 };
 
 // Views: view row r of a launch with stride row_mul and block size B = 1 << vshift is database row
@@ -628,7 +636,14 @@ __device__ __forceinline__ void sched_spread()
 // its staging loads are non-temporal and do not displace the queries (re-read by every workgroup
 // each K step) from L2 / Infinity Cache -- 10 M x 32 queries +4 %.  With several query tiles the
 // workgroups of a chunk share the rows through L2 and non-temporal loads cost 3 %.
-template <int WM, int WN, int TM, int TN, bool L2, bool NTDB = false>
+// SYM: all-vs-all with the index's own rows as queries.  dot(x, y) = dot(y, x) bit for bit (the chain multiplies the same
+// pairs in the same order) and nrm(x) + nrm(y) commutes, so the score tile of (query tile I, database tile J) also holds
+// the scores of (query tile J, database tile I): only the tiles on and above the diagonal are multiplied -- half the
+// MFMA work.  Every off-diagonal tile is filtered twice: lane-wise for the queries of tile I (the resident tile, as
+// always), and row-wise for the rows of tile J taken as queries, whose survivors go straight to those queries' compact
+// arrays (they have no workgroup-local list here: the statistical seed keeps them few, an overflow raises the
+// verification flag and the search is redone the plain way).
+template <int WM, int WN, int TM, int TN, bool L2, bool NTDB = false, bool SYM = false>
 __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 {
     static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -649,11 +664,22 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
 
-    const int qtile = blockIdx.x % p.nqtiles;
-    const int chunk = blockIdx.x / p.nqtiles;
+    int qtile, chunk;
+    int64_t c_lo, c_hi;
+    if constexpr (SYM) {
+        static_assert(DT == QT, "square tiles");
+        const SymItem it = p.sym_items[blockIdx.x];
+        qtile = it.qtile;
+        chunk = 0;
+        c_lo = (int64_t)it.jt0 * DT;
+        c_hi = min(p.nb, c_lo + (int64_t)it.jcount * DT);
+    } else {
+        qtile = blockIdx.x % p.nqtiles;
+        chunk = blockIdx.x / p.nqtiles;
+        c_lo = ((int64_t)chunk * p.tiles_base + min(chunk, p.tiles_rem)) * DT;
+        c_hi = min(p.nb, c_lo + (int64_t)(p.tiles_base + (chunk < p.tiles_rem ? 1 : 0)) * DT);
+    }
     const int64_t q0 = (int64_t)qtile * QT;
-    const int64_t c_lo = ((int64_t)chunk * p.tiles_base + min(chunk, p.tiles_rem)) * DT;
-    const int64_t c_hi = min(p.nb, c_lo + (int64_t)(p.tiles_base + (chunk < p.tiles_rem ? 1 : 0)) * DT);
     const int KT = p.dp / 32;
     ListCtx L;
     L.s_thr = (float *)(smem + lds_main);
@@ -661,6 +687,9 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
     L.s_need = L.s_cnt + QT;
     int *s_base = L.s_need + 4;            // [QT] first slot of each query's survivors in its compact array
     float *s_yn = (float *)(s_base + QT);  // [DT] squared norms of the current tile's rows (L2 only)
+    float *s_thr2 = s_yn + DT;             // SYM: [DT] thresholds of the tile's rows taken as queries
+    int *s_cnt2 = (int *)(s_thr2 + DT);    // SYM: [WN][DT] survivors per row found by the waves of each query half
+    int *s_base2 = s_cnt2 + WN * DT;       // SYM: [DT] first slot reserved in each row's compact array
     L.lists = p.lists + (size_t)blockIdx.x * QT * p.cap;
     L.gthr = p.gthr + (size_t)qtile * QT;
     L.cap = p.cap;
@@ -719,6 +748,11 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
             // (visible after the K loop's barriers) instead of 16 * TM * TN scattered global loads
             // per lane at the end of the tile
             if (tid < DT) s_yn[tid] = p.yn[view_row(min(row0 + tid, p.nb - 1), p.row_mul, p.vshift)];
+        }
+        const bool off_diag = SYM && row0 != q0; // (square tiles: the diagonal tile starts at the query tile's first row)
+        if constexpr (SYM) {
+            if (tid < DT) // rows past the end are nobody's query: nothing beats -inf
+                s_thr2[tid] = row0 + tid < p.nb ? ord2f(__hip_atomic_load(&p.gthr[row0 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : -INFINITY;
         }
         // One K step of MFMA work from buffer `cur`.  `dma(n)` (n < NI) issues this wave's n-th
         // staging instruction of the NEXT K step; the NI of them are spread between the MFMAs so
@@ -822,6 +856,83 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
                     }
                     if (v <= thr && row < c_hi && qok && !(p.skip_mask >= 0 && ((int)(row >> p.vshift) & p.skip_mask) == 0))
                         L.append(ql, v, p.id_base + (uint32_t)view_row(row, p.row_mul, p.vshift), DT);
+                }
+            }
+        }
+        if constexpr (SYM) {
+            if (off_diag) {
+                // the same scores, read the other way round: row R of this tile is a query, the resident tile's rows
+                // are its candidates.  A (register, lane half) pair of one wave is one row R and 32 candidates.
+                auto score = [&](int a, int b, int r, float xnq) -> float {
+                    if constexpr (L2) {
+                        const float ynr = s_yn[(wm * TM + a) * 32 + 4 * lh + (r & 3) + 8 * (r >> 2)];
+                        const float v = __builtin_fmaf(-2.0f, acc[a][b][r], xnq + ynr);
+                        return v < 0.0f ? 0.0f : v;
+                    } else {
+                        return -acc[a][b][r];
+                    }
+                };
+                float xnq[TN];
+                bool cand_ok[TN];
+#pragma unroll
+                for (int b = 0; b < TN; b++) {
+                    const int64_t q = q0 + (wn * TN + b) * 32 + li;
+                    // a candidate must be a real row that the sample pass has not already handed on
+                    cand_ok[b] = q < p.nq && !(p.skip_mask >= 0 && ((int)(q >> p.vshift) & p.skip_mask) == 0);
+                    xnq[b] = 0.0f;
+                    if constexpr (L2) xnq[b] = p.xn[q < p.nq ? q : 0];
+                }
+                // pass A: survivors per row (this wave's 64 rows x its 64 candidates)
+#pragma unroll
+                for (int a = 0; a < TM; a++) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int rl = (wm * TM + a) * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
+                        const float thr2 = s_thr2[rl];
+                        int c_lo2 = 0, c_hi2 = 0;
+#pragma unroll
+                        for (int b = 0; b < TN; b++) {
+                            const float v = score(a, b, r, xnq[b]);
+                            const uint64_t m = __ballot(v <= thr2 && cand_ok[b]);
+                            c_lo2 += __popc((uint32_t)m);
+                            c_hi2 += __popc((uint32_t)(m >> 32));
+                        }
+                        if (li == 0) s_cnt2[wn * DT + rl] = lh ? c_hi2 : c_lo2;
+                    }
+                }
+                __syncthreads();
+                if (tid < DT) {
+                    int c = 0;
+#pragma unroll
+                    for (int w2 = 0; w2 < WN; w2++) c += s_cnt2[w2 * DT + tid];
+                    s_base2[tid] = c > 0 ? (int)atomicAdd(&p.qcnt[row0 + tid], (uint32_t)c) : 0;
+                }
+                __syncthreads();
+                // pass B: the keys, behind the survivors of the waves with a lower query half
+#pragma unroll
+                for (int a = 0; a < TM; a++) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int rl = (wm * TM + a) * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
+                        const float thr2 = s_thr2[rl];
+                        int pos = s_base2[rl];
+                        for (int w2 = 0; w2 < wn; w2++) pos += s_cnt2[w2 * DT + rl];
+                        uint64_t *dst = p.qlist + (size_t)(row0 + rl) * p.qcap;
+#pragma unroll
+                        for (int b = 0; b < TN; b++) {
+                            const float v = score(a, b, r, xnq[b]);
+                            const bool pass = v <= thr2 && cand_ok[b];
+                            const uint64_t m = __ballot(pass);
+                            const uint32_t mh = lh ? (uint32_t)(m >> 32) : (uint32_t)m;
+                            if (pass) {
+                                const int at = pos + __popc(mh & ((1u << li) - 1u));
+                                const uint32_t id = p.id_base + (uint32_t)(q0 + (wn * TN + b) * 32 + li);
+                                if (at < p.qcap) dst[at] = ((uint64_t)f2ord(v + 0.0f) << 32) | id;
+                                else *p.fail = 1;
+                            }
+                            pos += __popc(mh);
+                        }
+                    }
                 }
             }
         }
@@ -1368,6 +1479,8 @@ struct knn_index_s {
     DevBuf ws_q, ws_qn, ws_lists, ws_D, ws_I, ws_tmp, ws_tmp2;
     DevBuf ws_D1, ws_I1, ws_tmp3; // second set for the pipelined host search
     DevBuf ws_flag;               // [0]: a statistically seeded search failed its verification
+    DevBuf ws_sym;                // work table of a symmetric all-vs-all launch
+    int64_t sym_searches = 0;     // self-searches served by the symmetric path
     static const int MAX_LEVELS = 8;
     LevelBufs ws_level[MAX_LEVELS]; // per seed-recursion level
     int last_seed_stride = 0, last_seed_stat = 0;
@@ -1551,7 +1664,7 @@ extern "C" void knn_free(knn_handle h)
         if (h->stream) (void)hipStreamSynchronize(h->stream);
         if (!h->is_view && h->xb) (void)hipDeviceSynchronize(); // a view's stream may still be scanning these rows
         free_index_buffers(h);
-        DevBuf *bufs[] = {&h->ws_flag, &h->ws_q, &h->ws_qn, &h->ws_lists, &h->ws_D, &h->ws_I, &h->ws_tmp, &h->ws_tmp2, &h->ws_D1, &h->ws_I1, &h->ws_tmp3};
+        DevBuf *bufs[] = {&h->ws_sym, &h->ws_flag, &h->ws_q, &h->ws_qn, &h->ws_lists, &h->ws_D, &h->ws_I, &h->ws_tmp, &h->ws_tmp2, &h->ws_D1, &h->ws_I1, &h->ws_tmp3};
         for (DevBuf *b : bufs) b->release();
         for (LevelBufs &b : h->ws_level) {
             b.qlist.release();
@@ -2179,6 +2292,110 @@ extern "C" int knn_merge_keys_dev(knn_handle h, const uint64_t *keys_dev, int32_
     return 0;
 }
 
+// Symmetric all-vs-all: index.search(x, k) for x = ALL rows of the index (cath/search.py:22-24,
+// pfam/proteins_search.py:37,49, pfam/slices/slices_search.py:22-28 -- every flat search of the reference is one).
+// Only the score tiles on and above the diagonal are multiplied (flat_scan_kernel<..., SYM>); needs the statistical
+// seed (the rows of a database tile have no candidate list of their own in that kernel, only their compact arrays)
+// and k <= 1536.  Returns 1 when it ran (D_dev / I_dev hold all n x k results, the verification flag is still to be
+// read by the caller), 0 when the plain path should be used, < 0 on error.
+static int self_search_symmetric(knn_index_s *h, int k, float *D_dev, int64_t *I_dev, hipStream_t s)
+{
+    const int64_t n = h->ntotal;
+    if (n < 8192 || k > KNN_WAVE_SELECT_MAX_K || k >= n || (h->flags & (8 | 16 | 512 | 1024)) || h->force_qt || h->force_chunks) return 0;
+    const int st = n >= (1 << 20) ? 64 : 32;
+    const int64_t S = view_rows(n, st, 0);
+    const int j = stat_seed_rank(S, n, k);
+    if (j <= 0) return 0;
+    const double expect = 1.3 * (double)j * (double)n / (double)S + 1.25 * k;
+    const int qcap = (int)std::min<double>(((int64_t)(2.0 * expect) + 1024 + 63) / 64 * 64, 1 << 20);
+    if ((double)n * qcap * 8.0 > 24.0 * (1u << 30)) return 0;
+    ScanPlan pl;
+    make_plan(h, n, n, k, true, pl); // (tile shape, list capacity, LDS)
+    if (pl.qt != 128 || pl.dt != 128) return 0;
+    const int T = (int)((n + 127) / 128);
+    const size_t nslots = (size_t)T * 128;
+    LevelBufs &lb = h->ws_level[0];
+    if (lb.qlist.ensure((size_t)n * qcap * 8) || lb.qcnt.ensure((size_t)n * 4) || lb.gthr.ensure(nslots * 4) || lb.qthr.ensure((size_t)n * 4) ||
+        h->ws_flag.ensure(64))
+        return set_err(KNN_ERR_HIP, "search_self: out of device memory");
+    uint64_t *qlist = (uint64_t *)lb.qlist.p;
+    uint32_t *qcnt = (uint32_t *)lb.qcnt.p, *gthr = (uint32_t *)lb.gthr.p, *qthr = (uint32_t *)lb.qthr.p;
+    const float *xn = h->metric == KNN_METRIC_L2 ? h->yn : nullptr; // the queries are the rows: their norms are the row norms
+    // 1. the sample pass (every row is a query, the strided sample is the database): thresholds + the sample's own candidates
+    SearchOut so;
+    so.keys = qlist; so.keys_stride = qcap; so.keys_fill = 0;
+    so.seed_cnt = qcnt; so.seed_gthr = gthr; so.seed_qthr = qthr; so.seed_j = j; so.seed_stat = 1; so.seed_nslots = (int64_t)nslots;
+    const int k_sample = std::min(k, j + std::max(j >> 2, 8) + 8);
+    int rc = search_view(h, h->xb, xn, n, k_sample, 0, st, 0, 1, so, false, s, (int *)h->ws_flag.p);
+    if (rc) return rc;
+    // 2. work table: workgroup = (query tile I, a run of database tiles J >= I).  The run length that minimises
+    //    rounds x (tiles + half a tile of fixed work), two workgroups per CU
+    const int64_t slots = 2 * (int64_t)std::max(1, h->num_cus);
+    int best_tp = 16;
+    int64_t best_cost = INT64_MAX;
+    for (int tp = 6; tp <= 96; tp++) {
+        int64_t wgs = 0;
+        for (int I = 0; I < T; I++) wgs += (T - I + tp - 1) / tp;
+        const int64_t rounds = (wgs + slots - 1) / slots;
+        const int64_t cost = rounds * (2 * tp + 1);
+        if (cost < best_cost || (cost == best_cost && tp > best_tp)) { best_cost = cost; best_tp = tp; }
+    }
+    std::vector<SymItem> items;
+    for (int I = 0; I < T; I++)
+        for (int j0 = I; j0 < T; j0 += best_tp) items.push_back({I, j0, std::min(best_tp, T - j0)});
+    // long runs first: the short tails of every query tile fill the last round
+    std::stable_sort(items.begin(), items.end(), [](const SymItem &a, const SymItem &b) { return a.jcount > b.jcount; });
+    if (h->ws_sym.ensure(items.size() * sizeof(SymItem))) return set_err(KNN_ERR_HIP, "search_self: out of device memory");
+    HIP_TRY(hipMemcpyAsync(h->ws_sym.p, items.data(), items.size() * sizeof(SymItem), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s)); // (the table is a local vector)
+    const size_t per_wg = (size_t)pl.qt * pl.cap * 8;
+    const int64_t max_wgs = std::max<int64_t>(slots, (int64_t)((2ull << 30) / per_wg));
+    if (h->ws_lists.ensure((size_t)std::min<int64_t>((int64_t)items.size(), max_wgs) * per_wg)) return set_err(KNN_ERR_HIP, "search_self: out of device memory (candidate lists)");
+    ScanParams p = {};
+    p.xb = h->xb; p.yn = h->yn; p.xq = h->xb; p.xn = xn;
+    p.nb = n; p.nq = n; p.dp = h->dp; p.k = k; p.cap = pl.cap;
+    p.nqtiles = T; p.nchunks = 1; p.tiles_base = 0; p.tiles_rem = 0;
+    p.lists = (uint64_t *)h->ws_lists.p; p.gthr = gthr;
+    p.qlist = qlist; p.qcnt = qcnt; p.qcap = qcap;
+    p.id_base = 0; p.row_mul = 1; p.vshift = 0; p.skip_mask = st - 1;
+    p.kslot = knn_kslot(k);
+    p.fail = (int *)h->ws_flag.p;
+    const size_t lds = pl.lds + (size_t)(2 + 2) * pl.dt * 4; // + thresholds, per-half counts and bases of the tile's rows
+    void (*kern)(ScanParams) = h->metric == KNN_METRIC_L2 ? flat_scan_kernel<2, 2, 2, 2, true, false, true> : flat_scan_kernel<2, 2, 2, 2, false, false, true>;
+    HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+        const int slot = (int)(h->nlaunches % knn_index_s::RING);
+        if (!h->ring0[slot]) {
+            HIP_TRY(hipEventCreate(&h->ring0[slot]));
+            HIP_TRY(hipEventCreate(&h->ring1[slot]));
+        }
+        h->ev0 = h->ring0[slot];
+        h->ev1 = h->ring1[slot];
+        h->nlaunches++;
+        HIP_TRY(hipEventRecord(h->ev0, s));
+    }
+    for (size_t i0 = 0; i0 < items.size(); i0 += (size_t)max_wgs) {
+        const size_t cnt = std::min<size_t>((size_t)max_wgs, items.size() - i0);
+        p.sym_items = (const SymItem *)h->ws_sym.p + i0;
+        hipLaunchKernelGGL(kern, dim3((unsigned)cnt), dim3(256), lds, s, p);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(h->ev1, s));
+    h->last_kernel = "flat_scan_q128_d128_sym"; h->last_qt = 128; h->last_dt = 128; h->last_chunks = best_tp; h->last_grid = (int)items.size();
+    h->last_seed_stride = st; h->last_seed_stat = j; h->last_sample_rows = S;
+    // 3. final selection of all n queries, verified against the sample's bound
+    SelectParams sp = {};
+    sp.in = qlist; sp.in_stride = qcap; sp.cnt = qcnt; sp.cap = qcap;
+    sp.n_expect = (int)std::min<double>((double)qcap, expect);
+    sp.nq = n; sp.k = k; sp.metric = h->metric;
+    sp.D = D_dev; sp.I = I_dev;
+    sp.qthr = qthr; sp.fail = (int *)h->ws_flag.p;
+    rc = launch_select(sp, s, &h->ws_tmp);
+    if (rc) return rc;
+    h->sym_searches++;
+    return 1;
+}
+
 // Copy streams of the pipelined host search: one set per device for the whole process, created on
 // first use (a HIP stream costs milliseconds to create and callers such as cath/search.py build a
 // fresh index per file).  Whoever holds `mu` pipelines; a concurrent host search on the same
@@ -2364,7 +2581,64 @@ extern "C" int knn_flat_search_self(knn_handle h, int64_t row0, int64_t nrows, i
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(h->mu);
     if (row0 < 0 || nrows < 0 || row0 + nrows > h->ntotal) return set_err(KNN_ERR_INVALID, "search_self: row range out of bounds");
+    if (row0 == 0 && nrows == h->ntotal && (size_t)nrows * k * 12 <= ((size_t)16 << 30)) {
+        // every row against every row: half the score tiles suffice (self_search_symmetric)
+        HIP_TRY(hipSetDevice(h->device));
+        if (h->ws_D.ensure((size_t)nrows * k * 4) || h->ws_I.ensure((size_t)nrows * k * 8)) return set_err(KNN_ERR_HIP, "search_self: out of device memory");
+        h->last_ms = -1.f;
+        rc = self_search_symmetric(h, (int)k, (float *)h->ws_D.p, (int64_t *)h->ws_I.p, h->stream);
+        if (rc < 0) return rc;
+        if (rc == 1) {
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            bool failed = false;
+            rc = search_failed(h, &failed);
+            if (rc) return rc;
+            if (!failed) {
+                HIP_TRY(hipMemcpyAsync(D_host, h->ws_D.p, (size_t)nrows * k * 4, hipMemcpyDeviceToHost, h->stream));
+                HIP_TRY(hipMemcpyAsync(I_host, h->ws_I.p, (size_t)nrows * k * 8, hipMemcpyDeviceToHost, h->stream));
+                HIP_TRY(hipStreamSynchronize(h->stream));
+                return 0;
+            }
+            // a threshold estimate was too tight or a candidate array overflowed: the plain path repeats the search
+        }
+    }
     return host_search(h, nullptr, row0, nrows, k, D_host, I_host);
+}
+
+// the same with the results left on the device (D_dev [ntotal][k], I_dev [ntotal][k]); synchronous
+extern "C" int knn_flat_search_self_dev(knn_handle h, int64_t k, float *D_dev, int64_t *I_dev)
+{
+    if (!h) return set_err(KNN_ERR_INVALID, "search_self: null handle");
+    if (h->ntotal == 0) return 0;
+    int rc = check_search_args(h, D_dev, h->ntotal, k, D_dev, I_dev);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    h->last_ms = -1.f;
+    rc = self_search_symmetric(h, (int)k, D_dev, I_dev, s);
+    if (rc < 0) return rc;
+    if (rc == 1) {
+        HIP_TRY(hipStreamSynchronize(s));
+        bool failed = false;
+        rc = search_failed(h, &failed);
+        if (rc) return rc;
+        if (!failed) return 0;
+    }
+    const int64_t QB = 16384;
+    for (int64_t b0 = 0; b0 < h->ntotal; b0 += QB) {
+        const int64_t m = std::min(QB, h->ntotal - b0);
+        for (int attempt = 0; attempt < 2; attempt++) { // (statistical seed first, plain if its verification fails)
+            rc = search_keys_impl(h, h->xb + (size_t)b0 * h->dp, m, (int)k, 0, nullptr, D_dev + b0 * k, I_dev + b0 * k, attempt == 0, s);
+            if (rc) return rc;
+            HIP_TRY(hipStreamSynchronize(s));
+            bool failed = false;
+            rc = search_failed(h, &failed);
+            if (rc) return rc;
+            if (!failed) break;
+        }
+    }
+    return 0;
 }
 
 extern "C" int knn_flat_normalize_rows(knn_handle h)

@@ -84,7 +84,7 @@ def test_config2_flat_l2_k100_200k(gpu_faiss, oracle):
     idx = gpu_faiss.IndexFlat(d, gpu_faiss.METRIC_L2)
     idx.add(x)
     D, I = idx.search_self(k)
-    assert idx.last_scan()["kernel"] == "flat_scan_q128_d128"
+    assert idx.last_scan()["kernel"] == "flat_scan_q128_d128_sym", "every row against every row: the symmetric launch"
     assert D.shape == (n, k) and (np.diff(D, axis=1) >= 0).all() and I.min() >= 0 and I.max() < n
     assert (I[:, 0] == np.arange(n)).all() and (D[:, 0] == 0).all(), "self hit first at distance exactly 0"
     D2, I2 = idx.search(x, k)

@@ -319,6 +319,50 @@ def test_large_results_live_in_page_locked_memory(gpu_faiss, oracle):
     assert small.search(xq[:10], 5)[0].flags.owndata  # small results stay plain numpy
 
 
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("n,d,k", [(9000, 64, 10), (14433, 128, 301), (20011, 32, 1000)])
+def test_symmetric_self_search_matches_plain_and_oracle(gpu_faiss, oracle, n, d, k, metric):
+    """search_self over the whole index multiplies only the score tiles on and above the diagonal (every tile serves the
+    queries of its row tile and of its column tile); flags=1024 forces the plain launch.  Same bits, with duplicates,
+    a ragged last tile and k up to 1000; oracle bits on sampled rows."""
+    rng = np.random.default_rng(n + k)
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    x[n - 300:n - 200] = x[100:200]          # exact duplicates across distant tiles: ties broken by the lower id
+    x[5000:5050] = x[4950:5000]
+    idx = gpu_faiss.IndexFlat(d, metric)
+    idx.add(x)
+    D, I = idx.search_self(k)
+    assert idx.last_scan()["kernel"] == "flat_scan_q128_d128_sym" and idx.last_seed()["stat_rank"] > 0
+    idx.set_tuning(0, 0, 1024)
+    Dp, Ip = idx.search_self(k)
+    assert idx.last_scan()["kernel"] == "flat_scan_q128_d128"
+    _assert_same(D, I, Dp, Ip)
+    sample = np.concatenate([rng.choice(n, 24, replace=False), [0, 127, 128, n - 1, 100, n - 300, 5000, 4950]])
+    Do, Io = oracle.flat_search(x, x[sample], k, metric)
+    _assert_same(D[sample], I[sample], Do, Io)
+
+
+def test_symmetric_self_search_repairs_a_failed_estimate(gpu_faiss, oracle):
+    """The adversarial database of the statistical-seed test, searched against itself: the sampled rows form a tight
+    cluster nobody else belongs to, their thresholds promise neighbours that do not exist, the symmetric launch's
+    verification fails and the plain path repeats the search -- exact result."""
+    rng = np.random.default_rng(77)
+    n, d, k = 16384, 64, 100
+    base = rng.standard_normal(d).astype(np.float32)
+    base /= np.linalg.norm(base)
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    near = np.arange(0, n, 32)
+    x[near] = base[None, :] + 0.05 * rng.standard_normal((near.size, d)).astype(np.float32)
+    idx = gpu_faiss.IndexFlat(d, 0)
+    idx.add(x)
+    before = idx.last_seed()["stat_redo"]
+    D, I = idx.search_self(k)
+    assert idx.last_seed()["stat_redo"] > before
+    sample = np.concatenate([near[:20], rng.choice(n, 20, replace=False)])
+    _assert_same(D[sample], I[sample], *oracle.flat_search(x, x[sample], k, 0))
+
+
 def test_normalize_matches_oracle(gpu_faiss, oracle):
     rng = np.random.default_rng(11)
     for n, d in ((1000, 1024), (333, 100), (50, 37), (1, 1024), (129, 8)):
