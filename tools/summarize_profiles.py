@@ -25,12 +25,12 @@ if bench_json.exists():
 
 
 def short(name):
-    # flat_scan_kernel<WM, WN, TM, TN, L2, NTDB>: a seed sample's pass is a small launch of the same instantiation;
+    # flat_scan_kernel<WM, WN, TM, TN, L2, NTDB, SYM>: a seed sample's pass is a small launch of the same instantiation;
     # the metric is part of the name (the bench's main config is inner product, its batch config L2)
     if "flat_scan_kernel<" in name:
         targs = name[name.index("flat_scan_kernel<") + len("flat_scan_kernel<"):].split(">")[0].split(", ")
         tile = {"4, 1, 2, 1": "flat_scan_q32_d256", "2, 2, 2, 1": "flat_scan_q64_d128", "2, 2, 2, 2": "flat_scan_q128_d128"}[", ".join(targs[:4])]
-        return tile + ("_l2" if targs[4] == "true" else "_ip")
+        return tile + ("_l2" if targs[4] == "true" else "_ip") + ("_sym" if len(targs) > 6 and targs[6] == "true" else "")
     return name.split("(")[0].replace("void ", "")[:60]
 
 
