@@ -237,6 +237,13 @@ def run(args):
         out["collective"] = {"op": "all_gather_into_tensor", "backend": "gloo (one-GPU rehearsal)" if rehearse else "nccl (RCCL)",
                              "bytes_per_rank": nq * k * 8, "avg_ms": gather_ms,
                              "note": "HIP events on the lane's stream around the collective of every timed step (rank 0)"}
+    basis = "HIP events around the scan launch on its stream"
+    if avg_scan_ms and in_flight == 2:
+        # two searches in flight: the two lanes' scan launches share the GPU, so the event pair around ONE launch spans
+        # the other's work too (measured 11.1 ms per launch against 7.2 ms per step).  The step time is the honest
+        # denominator there: one scan's bytes per step.
+        avg_scan_ms = 1e3 * elapsed / args.steps
+        basis = "ms_per_step (two searches in flight: per-launch event durations overlap)"
     if avg_scan_ms:
         achieved = alg_bytes / (avg_scan_ms * 1e-3) / 1e9
         traffic, traffic_source = None, None
@@ -254,7 +261,7 @@ def run(args):
         out["roofline"] = {
             "bound": "hbm", "kernel": info["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-            "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": avg_scan_ms,
+            "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": avg_scan_ms, "duration_basis": basis,
             "launches_timed": len(scan_ms), "db_passes": passes, "grid": info["grid"],
             "rows_per_launch": rows_kernel, "seed_sample_rows": seed["sample_rows"],
             "mfma_tflops": 2.0 * nq * rows_kernel * d / (avg_scan_ms * 1e-3) / 1e12,
