@@ -593,7 +593,7 @@ __device__ __forceinline__ void lists_compact(ListCtx &L, char *smem, int tile_r
 // wave per query.  qcap = (lists per query) x kslot: the reservations can never run past it.
 template <int QT, int NT = 256>
 __device__ __forceinline__ void lists_flush(ListCtx &L, int *s_base, int64_t q0, int64_t nq, uint64_t *qlist, uint32_t *qcnt,
-                                            int qcap, int tid)
+                                            int qcap, int tid, int *fail = nullptr)
 {
     const int lane = tid & 63, wave = tid >> 6;
     const int nqv = (int)min((int64_t)QT, nq - q0);
@@ -608,6 +608,8 @@ __device__ __forceinline__ void lists_flush(ListCtx &L, int *s_base, int64_t q0,
         uint64_t *dst = qlist + (size_t)(q0 + ql) * qcap + base;
         for (int i = lane; i < n; i += 64)
             if (base + i < qcap) dst[i] = lst[i];
+        // (only a symmetric launch sizes the arrays by expectation: an overflow there repeats the search the plain way)
+        if (fail && lane == 0 && base + n > qcap) *fail = 1;
     }
 }
 
@@ -942,7 +944,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
         const bool last_tile = row0 + DT >= c_hi;
         if (*L.s_need || last_tile) lists_compact<QT>(L, smem, DT, last_tile, tid);
     }
-    lists_flush<QT>(L, s_base, q0, p.nq, p.qlist, p.qcnt, p.qcap, tid);
+    lists_flush<QT>(L, s_base, q0, p.nq, p.qlist, p.qcnt, p.qcap, tid, SYM ? p.fail : nullptr);
 }
 
 // ---------------------------------------------------------------------------
