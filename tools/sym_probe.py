@@ -29,8 +29,10 @@ def run(n, d, metric, k, label, clustered=False):
         info = idx.last_scan(); t = float(np.median(ts[1:]))
         fl = 2.0 * n * n * d
         print(f"{label} flags={flags}: {info['kernel']:26s} search {1e3*t:9.2f} ms  (last scan launch(es) {info['ms']:8.2f} ms)  {n/t:10.0f} q/s  "
-              f"{fl/t/1e12:6.1f} 'TFLOP/s' of the full matrix; seed {idx.last_seed()}", flush=True)
+              f"{fl/t/1e12:6.1f} 'TFLOP/s' of the full matrix; run length {info['nchunks']} grid {info['grid']}; seed {idx.last_seed()}", flush=True)
 run(14433, 1024, 1, 301, "cath L2 k=301 ")
+if len(sys.argv) > 1 and sys.argv[1] == "cath":
+    sys.exit(0)
 run(14433, 1024, 0, 11, "cath IP k=11  ")
 run(200000, 1024, 0, 100, "pfam IP k=100 ", clustered=True)
 run(200000, 1024, 0, 1000, "pfam IP k=1000", clustered=True)
