@@ -45,6 +45,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef const __attribute__((address_space(1))) f32x4 *gptr4; // explicit global (not flat) loads
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define KEY_PAD 0xFFFFFFFFFFFFFFFFull
 
@@ -152,6 +153,19 @@ __global__ void pad_rows_kernel(const float *__restrict__ src, int64_t n, int d,
         int64_t r = i / dp;
         int c = (int)(i - r * dp);
         dst[i] = c < d ? src[r * d + c] : 0.0f;
+    }
+}
+
+// dst[n][dp] (bf16) <- src[n][dp] (fp32), round to nearest even: the operand copies of an approximate (bf16) index
+__global__ void to_bf16_kernel(const float *__restrict__ src, int64_t total, __bf16 *__restrict__ dst)
+{
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    for (; i < total; i += (int64_t)gridDim.x * blockDim.x * 4) {
+        const f32x4 v = *(const f32x4 *)(src + i); // (total is a multiple of 64)
+        dst[i] = (__bf16)v[0];
+        dst[i + 1] = (__bf16)v[1];
+        dst[i + 2] = (__bf16)v[2];
+        dst[i + 3] = (__bf16)v[3];
     }
 }
 
@@ -645,7 +659,12 @@ __device__ __forceinline__ void sched_spread()
 // always), and row-wise for the rows of tile J taken as queries, whose survivors go straight to those queries' compact
 // arrays (they have no workgroup-local list here: the statistical seed keeps them few, an overflow raises the
 // verification flag and the search is redone the plain way).
-template <int WM, int WN, int TM, int TN, bool L2, bool NTDB = false, bool SYM = false>
+// BF16: the operands are bf16 copies of the rows (an index made approximate on purpose: the coarse entry scan of the
+// HNSW index, where only the neighbourhood matters and every returned distance is re-scored exactly afterwards).
+// A staged 128-byte row segment then holds 64 values instead of 32, the same 16-byte fragment feeds ONE
+// v_mfma_f32_32x32x16_bf16 instead of four fp32 MFMAs (1/16 of the matrix time), and everything else -- staging,
+// swizzle, lists, thresholds, selection -- is shared.  p.dp counts 4-byte units of a row here (d / 2).
+template <int WM, int WN, int TM, int TN, bool L2, bool NTDB = false, bool SYM = false, bool BF16 = false>
 __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 {
     static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -776,19 +795,28 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
                 for (int b = 0; b < TN; b++)
                     bf[t & 1][b] = *(const f32x4 *)(B + ((wn * TN + b) * 32 + li) * 128 + slot);
             };
-            constexpr int M = 4 * TM * TN; // MFMAs per sub-step
+            constexpr int M = BF16 ? TM * TN : 4 * TM * TN; // MFMAs per sub-step
             frag(0);
-            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+            if constexpr (!BF16) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
             auto substep = [&](auto t_tag) {
                 constexpr int t = decltype(t_tag)::value;
                 if constexpr (t < 3) frag(t + 1);
-#pragma unroll
-                for (int m = 0; m < 4; m++)
+                if constexpr (BF16) {
 #pragma unroll
                     for (int a = 0; a < TM; a++)
 #pragma unroll
                         for (int b = 0; b < TN; b++)
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t & 1][a][m], bf[t & 1][b][m], acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[t & 1][a]),
+                                                                                __builtin_bit_cast(bf16x8, bf[t & 1][b]), acc[a][b], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int m = 0; m < 4; m++)
+#pragma unroll
+                        for (int a = 0; a < TM; a++)
+#pragma unroll
+                            for (int b = 0; b < TN; b++)
+                                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t & 1][a][m], bf[t & 1][b][m], acc[a][b], 0, 0, 0);
+                }
                 // staging instructions [n0, n1) of the next K step belong to this sub-step; all of
                 // them go out in the first half of the K step so that the second half covers
                 // their latency before the next barrier's vmcnt(0)
@@ -799,11 +827,13 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
                 // pin the order: LDS reads of t+1, then the MFMAs of t with the staging
                 // instructions spread between them (left alone, the scheduler sinks the reads
                 // behind the MFMAs to save registers and the wait is exposed)
-                if constexpr (t < 3) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-                constexpr int nd = n1 - n0, per = M / (nd + 1);
-                static_assert(per >= 1, "more staging instructions than MFMAs in a sub-step");
-                sched_spread<nd, per>();
-                __builtin_amdgcn_sched_group_barrier(0x008, M - nd * per, 0);
+                if constexpr (!BF16) { // (the bf16 build is bound by staging, not by the matrix pipe: the compiler's order will do)
+                    if constexpr (t < 3) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+                    constexpr int nd = n1 - n0, per = M / (nd + 1);
+                    static_assert(per >= 1, "more staging instructions than MFMAs in a sub-step");
+                    sched_spread<nd, per>();
+                    __builtin_amdgcn_sched_group_barrier(0x008, M - nd * per, 0);
+                }
             };
             substep(std::integral_constant<int, 0>{});
             substep(std::integral_constant<int, 1>{});
@@ -1470,6 +1500,8 @@ struct knn_index_s {
     std::shared_ptr<std::atomic<int64_t>> storage_gen = std::make_shared<std::atomic<int64_t>>(0);
     int64_t view_gen = 0;
     float *xb = nullptr; // [cap_rows][dp]
+    bool approx16 = false;  // the scan multiplies bf16 copies of rows and queries (HNSW's coarse entry index: approximate on purpose)
+    DevBuf xb16, ws_q16;    // approx16: [cap_rows][dp] bf16 rows, [nq][dp] bf16 queries
     float *yn = nullptr; // [cap_rows + pad]
     size_t xb_bytes = 0, yn_bytes = 0; // allocation sizes (may exceed the row capacity: pooled)
     hipStream_t stream = nullptr;
@@ -1666,7 +1698,7 @@ extern "C" void knn_free(knn_handle h)
         if (h->stream) (void)hipStreamSynchronize(h->stream);
         if (!h->is_view && h->xb) (void)hipDeviceSynchronize(); // a view's stream may still be scanning these rows
         free_index_buffers(h);
-        DevBuf *bufs[] = {&h->ws_sym, &h->ws_flag, &h->ws_q, &h->ws_qn, &h->ws_lists, &h->ws_D, &h->ws_I, &h->ws_tmp, &h->ws_tmp2, &h->ws_D1, &h->ws_I1, &h->ws_tmp3};
+        DevBuf *bufs[] = {&h->xb16, &h->ws_q16, &h->ws_sym, &h->ws_flag, &h->ws_q, &h->ws_qn, &h->ws_lists, &h->ws_D, &h->ws_I, &h->ws_tmp, &h->ws_tmp2, &h->ws_D1, &h->ws_I1, &h->ws_tmp3};
         for (DevBuf *b : bufs) b->release();
         for (LevelBufs &b : h->ws_level) {
             b.qlist.release();
@@ -1736,6 +1768,34 @@ static int grow_index(knn_index_s *h, int64_t need_rows)
     return 0;
 }
 
+// bf16 copies of rows [r0, r0 + n) of an approximate index (kept beside the fp32 rows: reconstruct, norms and the
+// exact re-scoring use those)
+static int approx16_sync_rows(knn_index_s *h, int64_t r0, int64_t n, hipStream_t s)
+{
+    if (!h->approx16 || n <= 0) return 0;
+    const size_t need = (size_t)h->cap_rows * h->dp * 2;
+    if (h->xb16.bytes < need) {
+        // (regrown with the fp32 storage: convert everything that is there)
+        if (h->xb16.ensure(need)) return set_err(KNN_ERR_HIP, "add: out of device memory (bf16 rows)");
+        n += r0;
+        r0 = 0;
+    }
+    const int64_t total = n * h->dp;
+    const unsigned grid = (unsigned)std::min<int64_t>((total / 4 + 255) / 256, 65535);
+    hipLaunchKernelGGL(to_bf16_kernel, dim3(grid), dim3(256), 0, s, h->xb + (size_t)r0 * h->dp, total, (__bf16 *)h->xb16.p + (size_t)r0 * h->dp);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// before the first add: the index multiplies bf16 copies (rows padded to a multiple of 64 values)
+static int flat_set_approx16(knn_index_s *h)
+{
+    if (h->ntotal != 0) return set_err(KNN_ERR_INVALID, "approx16: the index already holds rows");
+    h->approx16 = true;
+    h->dp = round_up(h->d, 64);
+    return 0;
+}
+
 // appends rows that already live on the device ([n][d], contiguous)
 static int add_dev_impl(knn_index_s *h, const float *x_dev, int64_t n, hipStream_t s)
 {
@@ -1750,6 +1810,8 @@ static int add_dev_impl(knn_index_s *h, const float *x_dev, int64_t n, hipStream
     }
     // norms are kept for both metrics: reconstruct/HNSW-L2 need them and they cost one pass
     int rc = norms_dev_impl(dst, n, h->d, h->dp, h->yn + h->ntotal, s);
+    if (rc) return rc;
+    rc = approx16_sync_rows(h, h->ntotal, n, s);
     if (rc) return rc;
     h->ntotal += n;
     return 0;
@@ -1791,6 +1853,8 @@ extern "C" int knn_flat_add(knn_handle h, const float *x_host, int64_t n)
         float *dst = h->xb + (size_t)h->ntotal * h->dp;
         HIP_TRY(hipMemcpy(dst, x_host, (size_t)n * h->d * 4, hipMemcpyHostToDevice));
         rc = norms_dev_impl(dst, n, h->d, h->dp, h->yn + h->ntotal, h->stream);
+        if (rc) return rc;
+        rc = approx16_sync_rows(h, h->ntotal, n, h->stream);
         if (rc) return rc;
         h->ntotal += n;
     } else {
@@ -1911,7 +1975,10 @@ static int launch_scan_cfg(const knn_index_s *h, const ScanParams &p, const Scan
     const bool l2 = h->metric == KNN_METRIC_L2;
     void (*kern)(ScanParams) = nullptr;
     // one query tile: rows are read once, non-temporal staging loads
-    if (p.nqtiles == 1) kern = l2 ? flat_scan_kernel<WM, WN, TM, TN, true, true> : flat_scan_kernel<WM, WN, TM, TN, false, true>;
+    if (h->approx16) {
+        if (p.nqtiles == 1) kern = l2 ? flat_scan_kernel<WM, WN, TM, TN, true, true, false, true> : flat_scan_kernel<WM, WN, TM, TN, false, true, false, true>;
+        else kern = l2 ? flat_scan_kernel<WM, WN, TM, TN, true, false, false, true> : flat_scan_kernel<WM, WN, TM, TN, false, false, false, true>;
+    } else if (p.nqtiles == 1) kern = l2 ? flat_scan_kernel<WM, WN, TM, TN, true, true> : flat_scan_kernel<WM, WN, TM, TN, false, true>;
     else kern = l2 ? flat_scan_kernel<WM, WN, TM, TN, true, false> : flat_scan_kernel<WM, WN, TM, TN, false, false>;
     HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds));
     hipLaunchKernelGGL(kern, dim3(plan.grid), dim3(256), plan.lds, s, p);
@@ -2106,6 +2173,10 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     ScanParams p;
     p.xb = h->xb; p.yn = h->yn; p.xq = q_dev; p.xn = xn;
     p.nb = nb; p.nq = nq; p.dp = h->dp; p.k = k; p.cap = pl.cap;
+    if (h->approx16) { // bf16 rows and queries: a row is dp / 2 four-byte units
+        p.xb = (const float *)h->xb16.p;
+        p.dp = h->dp / 2;
+    }
     p.nqtiles = pl.nqtiles; p.nchunks = pl.nchunks; p.tiles_base = pl.tiles_base; p.tiles_rem = pl.tiles_rem;
     p.lists = (uint64_t *)h->ws_lists.p; p.gthr = gthr;
     p.qlist = qlist; p.qcnt = qcnt; p.qcap = qcap;
@@ -2165,6 +2236,15 @@ static int search_keys_impl(knn_index_s *h, const float *q_dev, int64_t nq, int 
         xn = (const float *)h->ws_qn.p;
     }
     if (h->ws_flag.ensure(64)) return set_err(KNN_ERR_HIP, "search: out of device memory");
+    if (h->approx16) {
+        // the scan reads bf16 queries (the fp32 ones above gave the exact norms)
+        if (h->ws_q16.ensure((size_t)nq * h->dp * 2)) return set_err(KNN_ERR_HIP, "search: out of device memory");
+        const int64_t total = nq * h->dp;
+        hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)std::min<int64_t>((total / 4 + 255) / 256, 65535)), dim3(256), 0, s, q_dev, total,
+                           (__bf16 *)h->ws_q16.p);
+        HIP_TRY(hipGetLastError());
+        q_dev = (const float *)h->ws_q16.p;
+    }
     SearchOut out;
     out.keys = keys_out; out.keys_stride = k; out.keys_fill = 0;
     out.D = D_out; out.I = I_out;
@@ -2303,7 +2383,7 @@ extern "C" int knn_merge_keys_dev(knn_handle h, const uint64_t *keys_dev, int32_
 static int self_search_symmetric(knn_index_s *h, int k, float *D_dev, int64_t *I_dev, hipStream_t s)
 {
     const int64_t n = h->ntotal;
-    if (n < 8192 || k > KNN_WAVE_SELECT_MAX_K || k >= n || (h->flags & (8 | 16 | 512 | 1024)) || h->force_qt || h->force_chunks) return 0;
+    if (n < 8192 || k > KNN_WAVE_SELECT_MAX_K || k >= n || (h->flags & (8 | 16 | 512 | 1024)) || h->force_qt || h->force_chunks || h->approx16) return 0;
     const int st = n >= (1 << 20) ? 64 : 32;
     const int64_t S = view_rows(n, st, 0);
     const int j = stat_seed_rank(S, n, k);
@@ -2653,6 +2733,8 @@ extern "C" int knn_flat_normalize_rows(knn_handle h)
     int rc = normalize_dev_impl(h->xb, h->ntotal, h->d, h->dp, h->stream);
     if (rc) return rc;
     rc = norms_dev_impl(h->xb, h->ntotal, h->d, h->dp, h->yn, h->stream);
+    if (rc) return rc;
+    rc = approx16_sync_rows(h, 0, h->ntotal, h->stream);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     return 0;

@@ -105,6 +105,33 @@ def test_entry_modes_and_host_walk_agree_in_quality(gpu_faiss, metric, monkeypat
     assert rec["coarse"] >= 0.95 and rec["coarse"] >= rec["descent"] - 0.02, rec
 
 
+@pytest.mark.parametrize("d", [128, 100])
+def test_bf16_coarse_scan_matches_fp32_coarse_scan_in_quality(gpu_faiss, d, monkeypatch):
+    """The coarse entry scan multiplies bf16 copies of the rows above level 0 (entry points only need the neighbourhood;
+    the beam's rows are re-scored in fp32).  Same graph quality and recall as the fp32 coarse scan
+    (KNN355_HNSW_COARSE_FP32=1), distances still flat-exact; d = 100 exercises the padding to 64 values."""
+    n, nq, k = 30000, 800, 50
+    x = _clustered(n, d, 300, 5)
+    gpu_faiss.normalize_L2(x)
+    flat = gpu_faiss.IndexFlat(d, 0)
+    flat.add(x)
+    Dt, It = flat.search(x[:nq], k)
+    rec = {}
+    for name, env in (("bf16", "0"), ("fp32", "1")):
+        monkeypatch.setenv("KNN355_HNSW_COARSE_FP32", env)
+        idx = gpu_faiss.IndexHNSWFlat(d, 32, 0)
+        idx.add(x)
+        idx.hnsw.efSearch = 128
+        D, I = idx.search(x[:nq], k)
+        rec[name] = _recall(I, It)
+        for r in range(50):
+            ref = dict(zip(It[r].tolist(), Dt[r].view(np.uint32).tolist()))
+            for j, v in zip(I[r].tolist(), D[r].view(np.uint32).tolist()):
+                if j in ref:
+                    assert ref[j] == v
+    assert rec["bf16"] >= 0.95 and abs(rec["bf16"] - rec["fp32"]) <= 0.01, rec
+
+
 def test_rows_wider_than_the_device_beam_use_the_host_walk(gpu_faiss):
     """The device beam serves rows of up to 1024 floats; wider embeddings (ESM-1b: 1280) fall back to the host walk with
     GPU distance batches -- same contract (flat-exact distances, -1 padding), recall against the flat search."""
