@@ -206,6 +206,11 @@ def run(args):
     alg_bytes = passes * rows_kernel * d * 4 + nq * d * 4 + nq * k * 12
     avg_scan_ms = float(np.mean(scan_ms)) if scan_ms else None
 
+    # ---- the other multi-GPU split: Pfam-sized all-vs-all, rows replicated, queries split ----------
+    allvsall = None
+    if not args.no_batch:
+        allvsall = query_sharded_all_vs_all(dev, L, _lib, faiss, rank, world, dist if use_pg else None)
+
     if rank != 0:
         dist.destroy_process_group()
         return None
@@ -267,6 +272,8 @@ def run(args):
             "mfma_tflops": 2.0 * nq * rows_kernel * d / (avg_scan_ms * 1e-3) / 1e12,
         }
 
+    if allvsall is not None:
+        out["all_vs_all_query_sharded"] = allvsall
     if world == 1 and not args.no_extras:
         out["sweep"] = nq_sweep(index, dev, L, _lib, d, k, nb_local)
         out["host_buffers"] = host_buffer_step(index, q.cpu().numpy(), k)
@@ -283,6 +290,68 @@ def run(args):
     if use_pg:
         dist.destroy_process_group()
     return json.dumps(out)
+
+
+def query_sharded_all_vs_all(dev, L, _lib, faiss, rank, world, dist):
+    """S-pfam: 200 000 clustered rows x 1024, cosine, k=100, all-vs-all.  Every rank holds all rows and
+    answers its contiguous slice of the queries (QueryShardedFlatIndex): no collective on the data path, the results
+    stay on the rank that computed them.  value = 200 000 / the slowest rank's time."""
+    from knn_for_homology_amd.sharded import QueryShardedFlatIndex
+    n, d, k, ncent = 200_000, 1024, 100, 2000
+    g = torch.Generator(device=dev)
+    g.manual_seed(21)  # the same rows on every rank
+    cent = torch.randn((ncent, d), generator=g, device=dev)
+    which = torch.randint(0, ncent, (n,), generator=g, device=dev)
+    x = cent[which] + 0.35 * torch.randn((n, d), generator=g, device=dev)
+    x[-1000:] = x[:1000]  # 0.5 % exact duplicates: the tie rule is on the path
+    _lib.check(L.knn_normalize_l2_dev(x.data_ptr(), n, d, None))
+    idx = QueryShardedFlatIndex(d, faiss.METRIC_INNER_PRODUCT, rank=rank, world=world)
+    idx.reserve(n)
+    idx.add_dev(x)
+    lo, hi = idx.query_bounds(n)
+    times = []
+    for it in range(3):
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        D, I = idx.search_dev(x, k)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        if it >= 1:
+            times.append(el)
+    # every query finds itself (or its duplicate with the lower id) first
+    first = I[:, 0]
+    own = torch.arange(lo, hi, device=dev)
+    ok = bool(((first == own) | (first == own - (n - 1000))).all().item())
+    t = float(np.median(times))
+    out = {"workload": f"S-pfam: {n}x{d} clustered, cosine k={k}, all-vs-all; rows replicated, queries split over {world} GPU(s), no collective",
+           "value": n / t, "unit": "queries/s", "ms": 1e3 * t, "queries_per_rank": hi - lo, "self_hit_first_on_rank0": ok,
+           "roofline": {"bound": "mfma", "achieved": 2.0 * n * n * d / t / 1e12 / world, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s per GPU",
+                        "frac": 2.0 * n * n * d / t / 1e12 / world / FP32_MFMA_PEAK_TF,
+                        "note": "whole search per GPU (sample pass, scan, selection), not the kernel alone"}}
+    if world == 1:
+        # one GPU and a whole-index self-search: the symmetric launch is available (only tiles on/above the diagonal)
+        Ds = torch.empty((n, k), device=dev, dtype=torch.float32)
+        Is = torch.empty((n, k), device=dev, dtype=torch.int64)
+        ts = []
+        for it in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _lib.check(L.knn_flat_search_self_dev(idx.backend.index._h, k, Ds.data_ptr(), Is.data_ptr()))
+            torch.cuda.synchronize()
+            if it >= 1:
+                ts.append(time.perf_counter() - t0)
+        same = bool(torch.equal(Is, I) and torch.equal(Ds.view(torch.int32), D.view(torch.int32)))
+        out["self_search_symmetric"] = {"ms": 1e3 * float(np.median(ts)), "queries_per_s": n / float(np.median(ts)),
+                                        "identical_to_plain_search": same}
+    del idx, x, D, I
+    torch.cuda.empty_cache()
+    return out
 
 
 def nq_sweep(index, dev, L, _lib, d, k, nb):

@@ -216,3 +216,72 @@ class ShardedFlatIndex:
         if D.is_cuda:
             torch.cuda.current_stream(D.device).synchronize()
         return D.cpu().numpy(), I.cpu().numpy()
+
+
+class QueryShardedFlatIndex:
+    """The other way to spread an all-vs-all over the GPUs ("alternative"): the database is
+    REPLICATED -- CATH (59 MB) and Pfam (819 MB) fit any one GPU many times over -- and the queries are split:
+    rank r answers queries [lo_r, hi_r) = ``shard_bounds(nq, world, r)`` against all rows.  No collective on the
+    data path at all; every query's result is computed by one rank with the single-GPU kernels, so it is the
+    single-GPU result bit for bit.  ``gather=True`` concatenates the slices on every rank with one all-gather of
+    D and one of I (padded to ceil(nq/world) rows per rank); the default leaves each rank with its own slice,
+    which is what a caller that writes per-rank output files wants (2.4 GB of results at Pfam size, k=1000)."""
+
+    def __init__(self, d, metric=_faiss.METRIC_L2, rank=None, world=None, group=None, backend=None):
+        self.d, self.metric_type, self.group = d, metric, group
+        if world is None:
+            world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if rank is None:
+            rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.rank, self.world = rank, world
+        self.backend = backend if backend is not None else HipShardBackend(d, metric)
+
+    @property
+    def ntotal(self):
+        return self.backend.ntotal
+
+    def reserve(self, n):
+        self.backend.reserve(n)
+
+    def add(self, x):
+        """Adds rows to THIS rank's replica: every rank adds the same rows in the same order."""
+        self.backend.add(x)
+
+    def add_dev(self, x):
+        self.backend.add_dev(x)
+
+    def query_bounds(self, nq):
+        return shard_bounds(nq, self.world, self.rank)
+
+    def search_dev(self, q, k, gather=False):
+        """q: [nq, d] float32 tensor, identical on every rank.  Returns (D, I) of this rank's query slice
+        (``query_bounds(nq)``), or of all nq queries on every rank with ``gather=True``."""
+        k = int(k)
+        nq = q.shape[0]
+        lo, hi = self.query_bounds(nq)
+        if hi > lo:
+            D, I = self.backend.search(q[lo:hi].contiguous(), k)
+        else:
+            D = torch.empty((0, k), dtype=torch.float32, device=q.device)
+            I = torch.empty((0, k), dtype=torch.int64, device=q.device)
+        if not gather or self.world == 1:
+            return D, I
+        per = (nq + self.world - 1) // self.world
+        Dp = torch.zeros((per, k), dtype=torch.float32, device=q.device)
+        Ip = torch.full((per, k), -1, dtype=torch.int64, device=q.device)
+        Dp[: hi - lo] = D
+        Ip[: hi - lo] = I
+        Dg = torch.empty((self.world * per, k), dtype=torch.float32, device=q.device)
+        Ig = torch.empty((self.world * per, k), dtype=torch.int64, device=q.device)
+        dist.all_gather_into_tensor(Dg, Dp, group=self.group)
+        dist.all_gather_into_tensor(Ig, Ip, group=self.group)
+        # (contiguous slices of ceil(nq/world) queries: rank-major concatenation is query order)
+        return Dg[:nq], Ig[:nq]
+
+    def search(self, x: np.ndarray, k, gather=True):
+        _faiss._check_matrix(x, self.d)
+        dev = getattr(self.backend, "device", torch.device("cpu"))
+        D, I = self.search_dev(torch.from_numpy(x).to(dev), k, gather=gather)
+        if D.is_cuda:
+            torch.cuda.current_stream(D.device).synchronize()
+        return D.cpu().numpy(), I.cpu().numpy()

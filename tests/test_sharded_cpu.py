@@ -90,6 +90,26 @@ def _worker(rank, world, port, metric, out_dir):
     dist.destroy_process_group()
 
 
+def _worker_qs(rank, world, port, metric, out_dir):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from knn_for_homology_amd.sharded import QueryShardedFlatIndex
+    from test_sharded_cpu import OracleShardBackend
+    rng = np.random.default_rng(78)
+    xb = rng.standard_normal((301, 32), dtype=np.float32)
+    idx = QueryShardedFlatIndex(32, metric, backend=OracleShardBackend(32, metric))
+    idx.add(xb)
+    D, I = idx.search(xb, 20)                      # all-vs-all, gathered: 301 queries over 3 ranks (101 + 101 + 99)
+    Dl, Il = idx.search(xb, 20, gather=False)      # this rank's slice only
+    D1, I1 = idx.search(xb[:2], 5)                 # fewer queries than ranks: the last rank's slice is empty
+    np.savez(Path(out_dir) / f"q{rank}.npz", D=D, I=I, Dl=Dl, Il=Il, D1=D1, I1=I1, bounds=np.array(idx.query_bounds(301)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -110,6 +130,26 @@ def test_two_rank_gloo_equals_unsharded(tmp_path, metric):
         assert np.array_equal(got["I"], Io), f"rank {r}: ids differ from the unsharded search"
         assert np.array_equal(got["D"].view(np.uint32), Do.view(np.uint32))
     assert (Io[9:, 0] == np.arange(10, 14)).all() and (Io[9:, 1] == np.arange(900, 904)).all()
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_three_rank_query_sharded_all_vs_all(tmp_path, metric):
+    """SURVEY 8(e) alternative: replicated rows, split queries, no data-path collective; the optional gather
+    returns the unsharded result on every rank."""
+    from oracle import knn_oracle as ko
+    mp.spawn(_worker_qs, args=(3, _free_port(), metric, str(tmp_path)), nprocs=3, join=True)
+    xb = np.random.default_rng(78).standard_normal((301, 32), dtype=np.float32)
+    Do, Io = ko.oracle().flat_search(xb, xb, 20, metric)
+    D1o, I1o = ko.oracle().flat_search(xb, xb[:2], 5, metric)
+    seen = []
+    for r in range(3):
+        got = np.load(tmp_path / f"q{r}.npz")
+        assert np.array_equal(got["I"], Io) and np.array_equal(got["D"].view(np.uint32), Do.view(np.uint32))
+        lo, hi = got["bounds"]
+        seen.append((lo, hi))
+        assert np.array_equal(got["Il"], Io[lo:hi]) and np.array_equal(got["Dl"].view(np.uint32), Do[lo:hi].view(np.uint32))
+        assert np.array_equal(got["I1"], I1o) and np.array_equal(got["D1"].view(np.uint32), D1o.view(np.uint32))
+    assert seen == [(0, 101), (101, 202), (202, 301)]
 
 
 def test_shard_bounds_cover_everything():

@@ -144,3 +144,30 @@ def test_in_library_rccl_single_rank(gpu_faiss, oracle):
         assert L.knn_comm_create(ident, 2, 2, 0, ctypes.byref(ctypes.c_void_p())) != 0  # rank out of range
     finally:
         L.knn_comm_free(comm)
+
+
+def test_query_sharded_slices_equal_the_unsharded_search(gpu_faiss, oracle):
+    """QueryShardedFlatIndex (rows replicated, queries split): rank r of 3 returns rows [lo_r, hi_r) of the
+    single-GPU result, bit for bit -- constructed with explicit rank/world, no process group needed without gather."""
+    import torch
+    from knn_for_homology_amd.sharded import QueryShardedFlatIndex, shard_bounds
+    rng = np.random.default_rng(31)
+    n, d, k = 4001, 256, 33
+    xb = rng.standard_normal((n, d), dtype=np.float32)
+    xb[3000:3010] = xb[:10]
+    dev = torch.device("cuda", 0)
+    x = torch.from_numpy(xb).to(dev)
+    for metric in (0, 1):
+        Do, Io = oracle.flat_search(xb, xb, k, metric)
+        covered = 0
+        for r in range(3):
+            idx = QueryShardedFlatIndex(d, metric, rank=r, world=3)
+            idx.add_dev(x)
+            lo, hi = idx.query_bounds(n)
+            assert (lo, hi) == shard_bounds(n, 3, r)
+            D, I = idx.search_dev(x, k)
+            torch.cuda.synchronize()
+            assert np.array_equal(I.cpu().numpy(), Io[lo:hi])
+            assert np.array_equal(D.cpu().numpy().view(np.uint32), Do[lo:hi].view(np.uint32))
+            covered += hi - lo
+        assert covered == n

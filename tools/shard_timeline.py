@@ -23,10 +23,19 @@ def _is_main(n):
     if "flat_scan_kernel<" not in n:
         return False
     targs = n[n.index("flat_scan_kernel<") + len("flat_scan_kernel<"):].split(">")[0].split(", ")
+    if len(targs) > 7 and targs[7] == "true":  # (bf16 coarse scan of the bench's HNSW leg)
+        return False
     return not (len(targs) > 6 and targs[6] == "true")
 
 
 main = [i for i, n in enumerate(names) if _is_main(n)]
+# the streaming steps only: the longest run of scans of one instantiation
+from itertools import groupby
+runs, pos = [], 0
+for key, grp in groupby(main, key=lambda i: names[i]):
+    g = list(grp)
+    runs.append(g)
+main = max(runs, key=len)
 if len(main) < show + 3:
     print("too few steps", len(main)); sys.exit(1)
 # take steps from the tail (steady state)
