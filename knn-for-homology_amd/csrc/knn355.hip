@@ -1632,6 +1632,7 @@ extern "C" int knn_flat_create(int32_t d, int32_t metric, knn_handle *out)
     h->dp = round_up(d, 32);
     h->metric = metric;
     h->device = g_device;
+    if (const char *e = getenv("KNN355_FLAGS")) h->flags = atoi(e); // (developer A/B runs: the tuning flags every index starts with)
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, g_device) == hipSuccess && cus > 0) h->num_cus = cus;
@@ -1648,8 +1649,12 @@ extern "C" int knn_flat_view(knn_handle parent, knn_handle *out)
 {
     if (!parent || !out) return set_err(KNN_ERR_INVALID, "flat_view: null argument");
     std::lock_guard<std::mutex> lk(parent->mu);
+    if (parent->approx16) return set_err(KNN_ERR_UNSUPPORTED, "flat_view: not for an approximate (bf16) index");
     HIP_TRY(hipSetDevice(parent->device));
     knn_index_s *h = new knn_index_s();
+    h->flags = parent->flags;
+    h->force_qt = parent->force_qt;
+    h->force_chunks = parent->force_chunks;
     h->d = parent->d;
     h->dp = parent->dp;
     h->metric = parent->metric;
