@@ -680,3 +680,37 @@ def test_pfam_sized_all_vs_all(gpu_faiss, oracle):
     _assert_same(D[sample], I[sample], Do, Io)
     for r in rng.choice(n, 64, replace=False):  # no id twice in a row of results
         assert len(np.unique(I[r])) == k
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_device_search_of_many_queries_runs_in_blocks(gpu_faiss, oracle, metric):
+    """knn_flat_search_dev with more than 24576 queries launches blocks of 16384 (the last one ragged); synchronous
+    (statistical seed allowed, its verification flag accumulates over the blocks) and on a caller's stream (exact seed
+    only) -- same bits as the host path, oracle bits on sampled queries of every block."""
+    import ctypes
+    import torch
+    from knn_for_homology_amd import _lib
+    rng = np.random.default_rng(40 + metric)
+    nb, nq, d, k = 30000, 40001, 64, 20
+    xb = rng.standard_normal((nb, d), dtype=np.float32)
+    xq = rng.standard_normal((nq, d), dtype=np.float32)
+    xq[:500] = xb[:500]
+    idx = gpu_faiss.IndexFlat(d, metric)
+    idx.add(xb)
+    dev = torch.device("cuda", 0)
+    q = torch.from_numpy(xq).to(dev)
+    D = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    I = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    L = _lib.lib()
+    _lib.check(L.knn_flat_search_dev(idx._h, q.data_ptr(), nq, k, D.data_ptr(), I.data_ptr(), None))
+    Dh, Ih = idx.search(xq, k)
+    _assert_same(D.cpu().numpy(), I.cpu().numpy(), Dh, Ih)
+    side = torch.cuda.Stream(dev)
+    D2, I2 = torch.empty_like(D), torch.empty_like(I)
+    with torch.cuda.stream(side):
+        _lib.check(L.knn_flat_search_dev(idx._h, q.data_ptr(), nq, k, D2.data_ptr(), I2.data_ptr(), ctypes.c_void_p(side.cuda_stream)))
+    side.synchronize()
+    _assert_same(D2.cpu().numpy(), I2.cpu().numpy(), Dh, Ih)
+    sample = np.concatenate([rng.choice(nq, 40, replace=False), [0, 16383, 16384, 32767, 32768, nq - 1]])
+    Do, Io = oracle.flat_search(xb, xq[sample], k, metric)
+    _assert_same(Dh[sample], Ih[sample], Do, Io)
