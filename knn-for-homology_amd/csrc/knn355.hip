@@ -1501,6 +1501,7 @@ struct knn_index_s {
     int64_t view_gen = 0;
     float *xb = nullptr; // [cap_rows][dp]
     bool approx16 = false;  // the scan multiplies bf16 copies of rows and queries (HNSW's coarse entry index: approximate on purpose)
+    bool keep16 = false;    // bf16 copies of the rows are kept beside the fp32 ones (HNSW storage: the beam walks on them); scans stay fp32
     DevBuf xb16, ws_q16;    // approx16: [cap_rows][dp] bf16 rows, [nq][dp] bf16 queries
     float *yn = nullptr; // [cap_rows + pad]
     size_t xb_bytes = 0, yn_bytes = 0; // allocation sizes (may exceed the row capacity: pooled)
@@ -1777,7 +1778,7 @@ static int grow_index(knn_index_s *h, int64_t need_rows)
 // exact re-scoring use those)
 static int approx16_sync_rows(knn_index_s *h, int64_t r0, int64_t n, hipStream_t s)
 {
-    if (!h->approx16 || n <= 0) return 0;
+    if (!(h->approx16 || h->keep16) || n <= 0) return 0;
     const size_t need = (size_t)h->cap_rows * h->dp * 2;
     if (h->xb16.bytes < need) {
         // (regrown with the fp32 storage: convert everything that is there)
@@ -1798,6 +1799,14 @@ static int flat_set_approx16(knn_index_s *h)
     if (h->ntotal != 0) return set_err(KNN_ERR_INVALID, "approx16: the index already holds rows");
     h->approx16 = true;
     h->dp = round_up(h->d, 64);
+    return 0;
+}
+
+// before the first add: bf16 copies of the rows are kept (the scans do not use them)
+static int flat_keep16(knn_index_s *h)
+{
+    if (h->ntotal != 0) return set_err(KNN_ERR_INVALID, "keep16: the index already holds rows");
+    h->keep16 = true;
     return 0;
 }
 

@@ -267,3 +267,28 @@ def test_quality_matches_sequential_oracle(gpu_faiss, ko, metric):
         _, I = idx.search(x[:nq], 10)
         r_ref, r_gpu = _recall(Iref, It), _recall(I, It)
         assert r_gpu >= r_ref - 0.02, (efs, r_gpu, r_ref)
+
+
+def test_bf16_beam_matches_fp32_beam_in_quality(gpu_faiss, monkeypatch):
+    """The level-0 beam walks on bf16 copies of the rows (default) or on the fp32 rows (KNN355_HNSW_BEAM_FP32=1): same
+    recall within half a point, and in both every returned distance is the flat search's value for that pair."""
+    n, d, nq, k = 30000, 256, 800, 50
+    x = _clustered(n, d, 300, 9)
+    gpu_faiss.normalize_L2(x)
+    flat = gpu_faiss.IndexFlat(d, 0)
+    flat.add(x)
+    Dt, It = flat.search(x[:nq], k)
+    rec = {}
+    for name, env in (("bf16", "0"), ("fp32", "1")):
+        monkeypatch.setenv("KNN355_HNSW_BEAM_FP32", env)
+        idx = gpu_faiss.IndexHNSWFlat(d, 32, 0)
+        idx.add(x)
+        idx.hnsw.efSearch = 128
+        D, I = idx.search(x[:nq], k)
+        rec[name] = _recall(I, It)
+        for r in range(50):
+            ref = dict(zip(It[r].tolist(), Dt[r].view(np.uint32).tolist()))
+            for j, v in zip(I[r].tolist(), D[r].view(np.uint32).tolist()):
+                if j in ref:
+                    assert ref[j] == v
+    assert rec["bf16"] >= 0.95 and abs(rec["bf16"] - rec["fp32"]) <= 0.005, rec
