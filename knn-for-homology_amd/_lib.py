@@ -133,10 +133,15 @@ def device_count():
 # Large (D, I) arrays are numpy arrays over hipHostMalloc'ed blocks: the result download is then a single DMA
 # at PCIe line rate instead of a staged copy (CATH20-sized k=300 result: 52 MB).  Blocks come from a small
 # size-classed free list and return to it when the last view of the array dies; at most PINNED_LIMIT bytes
-# are ever outstanding (beyond that: plain numpy.empty).
+# are ever outstanding (beyond that: plain numpy.empty).  Page-locking is not free -- hipHostMalloc pins about
+# 4 GiB/s (3 GiB for a Pfam-sized k=1000 result: 0.7 s), a staged download into pageable memory loses about 0.08 s per
+# GB -- so a block larger than PINNED_FIRST_MAX is only allocated when its size class is asked for the SECOND time:
+# a script that searches once (pfam/proteins_search.py) never pays, a loop over files (cath/search.py) pays once.
 PINNED_MIN = 4 << 20
+PINNED_FIRST_MAX = 64 << 20
 PINNED_LIMIT = 4 << 30
 _pinned_free = {}    # size class -> [pointers]
+_pinned_seen = {}    # size class -> requests so far
 _pinned_out = 0      # bytes handed out or cached
 
 
@@ -166,7 +171,9 @@ def result_array(shape, dtype):
     free = _pinned_free.get(cls)
     ptr = free.pop() if free else None
     if ptr is None:
-        if _pinned_out + cls > PINNED_LIMIT:
+        seen = _pinned_seen.get(cls, 0)
+        _pinned_seen[cls] = seen + 1
+        if _pinned_out + cls > PINNED_LIMIT or (cls > PINNED_FIRST_MAX and seen == 0):
             return np.empty(shape, dt)
         ptr = lib().knn_host_alloc(cls)
         if not ptr:

@@ -317,6 +317,14 @@ def test_large_results_live_in_page_locked_memory(gpu_faiss, oracle):
     small = gpu_faiss.IndexFlat(32, 1)
     small.add(xb)
     assert small.search(xq[:10], 5)[0].flags.owndata  # small results stay plain numpy
+    # a block above PINNED_FIRST_MAX is page-locked from the second request of its size class on
+    big = 1 << 27
+    _lib._pinned_seen.pop(big, None)
+    first = _lib.result_array((big // 4 - 5,), np.float32)
+    second = _lib.result_array((big // 4 - 5,), np.float32)
+    assert first.flags.owndata and not second.flags.owndata
+    del first, second
+    gc.collect()
 
 
 @pytest.mark.parametrize("metric", [0, 1])
