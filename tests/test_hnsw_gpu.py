@@ -292,3 +292,25 @@ def test_bf16_beam_matches_fp32_beam_in_quality(gpu_faiss, monkeypatch):
                 if j in ref:
                     assert ref[j] == v
     assert rec["bf16"] >= 0.95 and abs(rec["bf16"] - rec["fp32"]) <= 0.005, rec
+
+
+def test_lazy_and_eager_clearing_of_the_visited_bitmaps_agree(gpu_faiss, monkeypatch):
+    """Graphs of millions of rows clear only the bitmap words a walk touched (KNN355_HNSW_CLEAR=lazy forces that on a
+    small graph; an overflowing list -- efSearch 1024 with 64 neighbours per node -- falls back to the full clear):
+    identical results to the eager clear, search after search, and a graph built under either is the same graph."""
+    n, d, nq, k = 20000, 64, 600, 20
+    x = _clustered(n, d, 200, 4)
+    res, graphs = {}, {}
+    for mode in ("eager", "lazy"):
+        monkeypatch.setenv("KNN355_HNSW_CLEAR", mode)
+        idx = gpu_faiss.IndexHNSWFlat(d, 32, 1)
+        idx.add(x)
+        graphs[mode] = idx.graph()[2]
+        out = []
+        for efs in (64, 1024, 64, 256):
+            idx.hnsw.efSearch = efs
+            out.append(idx.search(x[:nq], k))
+        res[mode] = out
+    assert np.array_equal(graphs["eager"], graphs["lazy"])
+    for (De, Ie), (Dl, Il) in zip(res["eager"], res["lazy"]):
+        assert np.array_equal(Ie, Il) and np.array_equal(De.view(np.uint32), Dl.view(np.uint32))
