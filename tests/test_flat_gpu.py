@@ -320,11 +320,13 @@ def test_large_results_live_in_page_locked_memory(gpu_faiss, oracle):
     # a block above PINNED_FIRST_MAX is page-locked from the second request of its size class on
     big = 1 << 27
     _lib._pinned_seen.pop(big, None)
+    cached = _lib._pinned_free.pop(big, [])   # (blocks of this class an earlier test may have left in the pool)
     first = _lib.result_array((big // 4 - 5,), np.float32)
     second = _lib.result_array((big // 4 - 5,), np.float32)
     assert first.flags.owndata and not second.flags.owndata
     del first, second
     gc.collect()
+    _lib._pinned_free.setdefault(big, []).extend(cached)
 
 
 @pytest.mark.parametrize("metric", [0, 1])
