@@ -681,7 +681,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // (scalar: the LDS targets of the staging instructions are then SGPR arithmetic, no v_readfirstlane per instruction)
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
 
@@ -818,9 +818,9 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
                                 acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t & 1][a][m], bf[t & 1][b][m], acc[a][b], 0, 0, 0);
                 }
                 // staging instructions [n0, n1) of the next K step belong to this sub-step; all of
-                // them go out in the first half of the K step so that the second half covers
+                // them go out in the first TD sub-steps of the K step so that the rest covers
                 // their latency before the next barrier's vmcnt(0)
-                constexpr int TD = 2;
+                constexpr int TD = NTDB ? 2 : 3; // (streaming launches wait for HBM: early; batch launches hit L2: spread wider, +1 %)
                 constexpr int n0 = t < TD ? ND * t / TD : ND, n1 = t < TD ? ND * (t + 1) / TD : ND;
 #pragma unroll
                 for (int n = n0; n < n1; n++) dma(n);
