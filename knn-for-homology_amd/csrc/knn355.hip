@@ -1919,7 +1919,11 @@ static const int KNN_SELECT_SEG = 32768;
 static int launch_select(SelectParams sp, hipStream_t s, DevBuf *tmp = nullptr)
 {
     if (sp.nq <= 0) return 0;
-    if (tmp && sp.lm_lists == 0 && sp.cnt && sp.cap > KNN_SELECT_SEG) {
+    // (an array whose CAPACITY is larger but which is expected to hold far fewer keys -- the compact arrays of an
+    // exactly seeded scan are sized for the worst case of every chunk -- goes straight to the one-launch selection:
+    // 32768 keys fit its registers, a longer array is re-read from L2 on every probe)
+    const bool expect_short = sp.n_expect > 0 && sp.n_expect <= 24576;
+    if (tmp && sp.lm_lists == 0 && sp.cnt && sp.cap > KNN_SELECT_SEG && !expect_short) {
         // Arrays of up to `cap` > 32768 keys (a seed sample of a 10 M-row database hands on 39 k scores per
         // query): workgroup (q, s) reduces segment s of query q to its kk = kmax best keys in registers, then
         // one more launch selects among the nseg * kk survivors -- two launches instead of re-reading the
@@ -2225,6 +2229,11 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     // final selection: every query's candidates (seed list + the chunks' survivors) -> sorted top-k
     SelectParams sp = {};
     sp.in = qlist; sp.in_stride = qcap; sp.cnt = qcnt; sp.cap = qcap;
+    if (expect_n <= 0 && sstride && !seed_stat) {
+        // exact seed: the sample's k-th score admits about k rows per sample-sized slice of the rest of the view
+        const double S = (double)view_rows(nb, sstride, p.vshift);
+        expect_n = 1.5 * (double)k * (double)nb / std::max(1.0, S) + 1.25 * k;
+    }
     if (expect_n <= 0) expect_n = (double)qcap;
     sp.n_expect = (int)std::min<double>(std::min<double>((double)qcap, expect_n), (double)nb); // (never more than the view has rows)
     sp.nq = nq; sp.k = k; sp.metric = h->metric;
