@@ -211,6 +211,10 @@ def run(args):
     if not args.no_batch:
         allvsall = query_sharded_all_vs_all(dev, L, _lib, faiss, rank, world, dist if use_pg else None)
 
+    hnsw_rep = None
+    if world > 1 and not args.no_extras:
+        hnsw_rep = hnsw_replicas(dev, L, _lib, faiss, rank, world, dist)
+
     if rank != 0:
         dist.destroy_process_group()
         return None
@@ -274,6 +278,8 @@ def run(args):
 
     if allvsall is not None:
         out["all_vs_all_query_sharded"] = allvsall
+    if hnsw_rep is not None:
+        out["hnsw_replicas"] = hnsw_rep
     if world == 1 and not args.no_extras:
         out["sweep"] = nq_sweep(index, dev, L, _lib, d, k, nb_local)
         out["host_buffers"] = host_buffer_step(index, q.cpu().numpy(), k)
@@ -535,6 +541,42 @@ def batch_config(dev, L, _lib, faiss):
             "self_search": self_search,
             "end_to_end": {"ms": 1e3 * float(np.median(e2e)), "queries_per_s": n / float(np.median(e2e)),
                            "what": "cath.search.search(numpy fp32[14433,1024], hits=300, L2): H2D 59 MB + add + search + D2H 52 MB"}}
+
+
+def hnsw_replicas(dev, L, _lib, faiss, rank, world, dist):
+    """HNSW does not shard (replicas only): every rank builds the same graph (the construction is
+    deterministic) over the S-pfam rows and answers its OWN 4096 queries; value = all ranks' queries / the slowest
+    rank's time.  No collective on the data path."""
+    n, d, k, nq = 200_000, 1024, 100, 4096
+    g = torch.Generator(device=dev)
+    g.manual_seed(21)
+    cent = torch.randn((2000, d), generator=g, device=dev)
+    which = torch.randint(0, 2000, (n,), generator=g, device=dev)
+    x = cent[which] + 0.35 * torch.randn((n, d), generator=g, device=dev)
+    _lib.check(L.knn_normalize_l2_dev(x.data_ptr(), n, d, None))
+    idx = faiss.IndexHNSWFlat(d, 32, faiss.METRIC_INNER_PRODUCT)
+    t0 = time.perf_counter()
+    idx.add_dev(x)
+    build_s = time.perf_counter() - t0
+    idx.hnsw.efSearch = 256
+    qh = x[torch.from_numpy(np.random.default_rng(26 + rank).choice(n, nq, replace=False)).to(dev)].cpu().numpy()
+    idx.search(qh[:256], k)
+    ts = []
+    for _ in range(3):
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        D, I = idx.search(qh, k)
+        el = time.perf_counter() - t0
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ts.append(float(t.item()))
+    tmed = float(np.median(ts))
+    self_first = float((I[:, 0] >= 0).mean())
+    del idx, x
+    torch.cuda.empty_cache()
+    return {"workload": f"BASELINE configs[4] as {world} replicas: 200000x1024 clustered, IP, HNSW M=32 efSearch=256, k=100, {nq} queries per rank",
+            "queries_per_s": world * nq / tmed, "build_s_rank0": build_s, "ms": 1e3 * tmed, "results_found_rank0": self_first}
 
 
 def hnsw_config(dev, L, _lib, faiss):
