@@ -34,6 +34,27 @@ def short(name):
     return name.split("(")[0].replace("void ", "")[:60]
 
 
+def by_grid(trace_csv, dest):
+    """per (kernel, workgroups) rows of the kernel trace: a seed sample's pass and the main scan are launches of
+    the SAME instantiation with different grids -- rocprofv3's --stats blends them into one average.  This is the
+    table the headline roofline fraction is recomputable from: algorithmic bytes / mean_ms of the main grid."""
+    import statistics
+    groups = collections.defaultdict(list)
+    for r in csv.DictReader(open(trace_csv)):
+        name = r["Kernel_Name"]
+        if not any(t in name for t in ("flat_scan_kernel", "select_topk", "init_level", "hamming_scan", "hnsw_beam", "beam_keys",
+                                        "segment", "pair_", "l2diff")):
+            continue
+        wg = max(1, int(r["Workgroup_Size_X"]))
+        groups[(short(name), name.split("(")[0].replace("void ", ""), int(r["Grid_Size_X"]) // wg, wg)].append(
+            (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
+    with open(dest, "w") as fh:
+        fh.write("kernel,instantiation,workgroups,workgroup_size,launches,mean_ms,median_ms,min_ms,max_ms,total_ms\n")
+        for (sh, full, grid, wg), ts in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
+            fh.write(f'{sh},"{full}",{grid},{wg},{len(ts)},{statistics.mean(ts):.4f},{statistics.median(ts):.4f},{min(ts):.4f},{max(ts):.4f},{sum(ts):.3f}\n')
+    return groups
+
+
 def per_kernel(path, counter):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
@@ -41,6 +62,23 @@ def per_kernel(path, counter):
             agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     return agg
 
+
+trace = go / f"prof_{tag}" / f"{tag}_kernel_trace.csv"
+if trace.exists():
+    groups = by_grid(trace, out / f"{tag}_bench_kernel_by_grid.csv")
+    if bench_json.exists():
+        try:
+            b = json.loads(bench_json.read_text().strip().splitlines()[-1])
+            rf = b["roofline"]
+            for (sh, full, grid, wg), ts in groups.items():
+                if sh == rf["kernel"] + "_ip" and grid == rf["grid"]:
+                    import statistics
+                    m = statistics.mean(ts)
+                    print(f"headline check: {rf['algorithmic_bytes_per_launch']} B / mean {m:.4f} ms of the {len(ts)} grid-{grid} launches "
+                          f"= {rf['algorithmic_bytes_per_launch'] / m / 1e6:.1f} GB/s = {rf['algorithmic_bytes_per_launch'] / m / 1e6 / 8000:.4f} of 8 TB/s "
+                          f"(the line under rocprofv3 says {rf['frac']:.4f} from {rf['avg_kernel_ms']:.4f} ms)")
+        except Exception as e:  # pragma: no cover
+            print("headline check failed:", e)
 
 fetch = per_kernel(go / f"pmc_fetch_{tag}" / "f_counter_collection.csv", "FETCH_SIZE")
 write = per_kernel(go / f"pmc_write_{tag}" / "w_counter_collection.csv", "WRITE_SIZE")
