@@ -8,7 +8,7 @@
  * (/root/reference/seqvec_search/main.py:45, cath/search.py:24, pfam/proteins_search.py:49) -- written the
  * way a maintainer would write it for a many-core x86 host, so that the number printed next to the GPU's
  * is one they would recognise: an OpenMP scan over contiguous row ranges, a register-blocked AVX-512 (or
- * AVX2+FMA) inner-product micro-kernel (4 rows x 4 queries, 16 vector accumulators), FAISS's L2 formula
+ * AVX2+FMA) sgemm-style micro-kernel (8 rows x 32 queries, 16 vector accumulators, no horizontal sums), FAISS's L2 formula
  * |x|^2 + |y|^2 - 2<x,y> clamped at 0 on top of it, a per-thread threshold + candidate buffer per query
  * (FAISS: a heap per query below k = 100, a reservoir from k = 100 on), and one final merge, best first,
  * ties to the lower row id.  Rows live in memory first-touched by the thread that scans them (NUMA).
@@ -120,87 +120,53 @@ double cpu_scan_read_seconds(const float *xb, int64_t n, int32_t d, int32_t thre
     return t1 - t0;
 }
 
-/* ---- micro-kernels: dots of 4 rows x 4 queries ------------------------------------------------ */
-__attribute__((target("avx512f"))) static void dots4x4_avx512(const float *y0, const float *y1, const float *y2,
-                                                              const float *y3, const float *q, int64_t qstride,
-                                                              int32_t d, float out[16]) {
-    __m512 c[16];
-    for (int i = 0; i < 16; i++) c[i] = _mm512_setzero_ps();
-    const float *q0 = q, *q1 = q + qstride, *q2 = q + 2 * qstride, *q3 = q + 3 * qstride;
-    int32_t j = 0;
-    for (; j + 16 <= d; j += 16) {
-        __m512 a0 = _mm512_loadu_ps(y0 + j), a1 = _mm512_loadu_ps(y1 + j);
-        __m512 a2 = _mm512_loadu_ps(y2 + j), a3 = _mm512_loadu_ps(y3 + j);
-        __m512 b = _mm512_loadu_ps(q0 + j);
-        c[0] = _mm512_fmadd_ps(a0, b, c[0]); c[4] = _mm512_fmadd_ps(a1, b, c[4]);
-        c[8] = _mm512_fmadd_ps(a2, b, c[8]); c[12] = _mm512_fmadd_ps(a3, b, c[12]);
-        b = _mm512_loadu_ps(q1 + j);
-        c[1] = _mm512_fmadd_ps(a0, b, c[1]); c[5] = _mm512_fmadd_ps(a1, b, c[5]);
-        c[9] = _mm512_fmadd_ps(a2, b, c[9]); c[13] = _mm512_fmadd_ps(a3, b, c[13]);
-        b = _mm512_loadu_ps(q2 + j);
-        c[2] = _mm512_fmadd_ps(a0, b, c[2]); c[6] = _mm512_fmadd_ps(a1, b, c[6]);
-        c[10] = _mm512_fmadd_ps(a2, b, c[10]); c[14] = _mm512_fmadd_ps(a3, b, c[14]);
-        b = _mm512_loadu_ps(q3 + j);
-        c[3] = _mm512_fmadd_ps(a0, b, c[3]); c[7] = _mm512_fmadd_ps(a1, b, c[7]);
-        c[11] = _mm512_fmadd_ps(a2, b, c[11]); c[15] = _mm512_fmadd_ps(a3, b, c[15]);
-    }
-    for (int i = 0; i < 16; i++) out[i] = _mm512_reduce_add_ps(c[i]);
-    if (j < d) {
-        const float *ys[4] = {y0, y1, y2, y3};
-        const float *qs[4] = {q0, q1, q2, q3};
-        for (int r = 0; r < 4; r++)
-            for (int s = 0; s < 4; s++) {
-                float t = 0.f;
-                for (int32_t jj = j; jj < d; jj++) t += ys[r][jj] * qs[s][jj];
-                out[r * 4 + s] += t;
-            }
-    }
-}
-
-__attribute__((target("avx2,fma"))) static float hsum256(__m256 v) {
-    __m128 lo = _mm256_castps256_ps128(v), hi = _mm256_extractf128_ps(v, 1);
-    lo = _mm_add_ps(lo, hi);
-    lo = _mm_hadd_ps(lo, lo);
-    lo = _mm_hadd_ps(lo, lo);
-    return _mm_cvtss_f32(lo);
-}
-/* AVX2 has 16 vector registers: 2 rows x 4 queries per pass, twice */
-__attribute__((target("avx2,fma"))) static void dots4x4_avx2(const float *y0, const float *y1, const float *y2,
-                                                             const float *y3, const float *q, int64_t qstride, int32_t d,
-                                                             float out[16]) {
-    const float *ys[4] = {y0, y1, y2, y3};
-    const float *q0 = q, *q1 = q + qstride, *q2 = q + 2 * qstride, *q3 = q + 3 * qstride;
-    for (int half = 0; half < 2; half++) {
-        const float *ya = ys[2 * half], *yb = ys[2 * half + 1];
-        __m256 c[8];
-        for (int i = 0; i < 8; i++) c[i] = _mm256_setzero_ps();
-        int32_t j = 0;
-        for (; j + 8 <= d; j += 8) {
-            __m256 a0 = _mm256_loadu_ps(ya + j), a1 = _mm256_loadu_ps(yb + j);
-            __m256 b = _mm256_loadu_ps(q0 + j);
-            c[0] = _mm256_fmadd_ps(a0, b, c[0]); c[4] = _mm256_fmadd_ps(a1, b, c[4]);
-            b = _mm256_loadu_ps(q1 + j);
-            c[1] = _mm256_fmadd_ps(a0, b, c[1]); c[5] = _mm256_fmadd_ps(a1, b, c[5]);
-            b = _mm256_loadu_ps(q2 + j);
-            c[2] = _mm256_fmadd_ps(a0, b, c[2]); c[6] = _mm256_fmadd_ps(a1, b, c[6]);
-            b = _mm256_loadu_ps(q3 + j);
-            c[3] = _mm256_fmadd_ps(a0, b, c[3]); c[7] = _mm256_fmadd_ps(a1, b, c[7]);
-        }
-        for (int i = 0; i < 8; i++) out[half * 8 + i] = hsum256(c[i]);
-        if (j < d) {
-            const float *qs[4] = {q0, q1, q2, q3};
-            for (int r = 0; r < 2; r++)
-                for (int s = 0; s < 4; s++) {
-                    float t = 0.f;
-                    for (int32_t jj = j; jj < d; jj++) t += ys[2 * half + r][jj] * qs[s][jj];
-                    out[half * 8 + r * 4 + s] += t;
-                }
+/* ---- micro-kernels: 8 rows x 32 queries (AVX-512) / 4 rows x 16 queries (AVX2) ------------------
+ * The queries are transposed once per search into groups qt[g][j][G] (G = 32 or 16 queries side by side), so the
+ * vector dimension runs over QUERIES: for every coordinate j one broadcast of the row's y[j] feeds two FMAs, the
+ * accumulators are the finished scores (no horizontal sums) and the threshold test is one vector compare per 16
+ * scores.  Per coordinate: 8 broadcasts + 2 query vectors loaded, 16 FMAs -- the shape of a BLAS sgemm micro-kernel
+ * with the top-k filter fused behind it.  A group's transposed queries (d x 32 x 4 B = 128 KB at d = 1024) stay in L2,
+ * the 8 rows (32 KB) in L1 across the groups. */
+#define ROWS512 8
+#define G512 32
+__attribute__((target("avx512f"))) static void scores_avx512(const float *const y[ROWS512], const float *qt, int32_t d,
+                                                             float *out /* [ROWS512][G512] */) {
+    __m512 c[ROWS512][2];
+    for (int r = 0; r < ROWS512; r++) c[r][0] = c[r][1] = _mm512_setzero_ps();
+    for (int32_t j = 0; j < d; j++) {
+        const __m512 b0 = _mm512_load_ps(qt + (size_t)j * G512), b1 = _mm512_load_ps(qt + (size_t)j * G512 + 16);
+#pragma GCC unroll 8
+        for (int r = 0; r < ROWS512; r++) {
+            const __m512 a = _mm512_set1_ps(y[r][j]);
+            c[r][0] = _mm512_fmadd_ps(a, b0, c[r][0]);
+            c[r][1] = _mm512_fmadd_ps(a, b1, c[r][1]);
         }
     }
+    for (int r = 0; r < ROWS512; r++) {
+        _mm512_storeu_ps(out + r * G512, c[r][0]);
+        _mm512_storeu_ps(out + r * G512 + 16, c[r][1]);
+    }
 }
-
-typedef void (*dots_fn)(const float *, const float *, const float *, const float *, const float *, int64_t, int32_t,
-                        float[16]);
+#define ROWS256 4
+#define G256 16
+__attribute__((target("avx2,fma"))) static void scores_avx2(const float *const y[ROWS256], const float *qt, int32_t d,
+                                                            float *out /* [ROWS256][G256] */) {
+    __m256 c[ROWS256][2];
+    for (int r = 0; r < ROWS256; r++) c[r][0] = c[r][1] = _mm256_setzero_ps();
+    for (int32_t j = 0; j < d; j++) {
+        const __m256 b0 = _mm256_load_ps(qt + (size_t)j * G256), b1 = _mm256_load_ps(qt + (size_t)j * G256 + 8);
+#pragma GCC unroll 4
+        for (int r = 0; r < ROWS256; r++) {
+            const __m256 a = _mm256_broadcast_ss(y[r] + j);
+            c[r][0] = _mm256_fmadd_ps(a, b0, c[r][0]);
+            c[r][1] = _mm256_fmadd_ps(a, b1, c[r][1]);
+        }
+    }
+    for (int r = 0; r < ROWS256; r++) {
+        _mm256_storeu_ps(out + r * G256, c[r][0]);
+        _mm256_storeu_ps(out + r * G256 + 8, c[r][1]);
+    }
+}
 
 static float dot_scalar(const float *a, const float *b, int32_t d) {
     float t = 0.f;
@@ -240,17 +206,21 @@ int cpu_scan_search(const float *xb, const float *yn, int64_t nb, const float *x
     if (nb < 0 || nq < 0 || d <= 0 || k <= 0 || (metric != 0 && metric != 1)) return -1;
     if (metric == 1 && !yn && nb > 0) return -1;
     if (threads <= 0) threads = omp_get_max_threads();
-    dots_fn dots = cpu_scan_has_avx512() ? dots4x4_avx512 : dots4x4_avx2;
+    const int wide = cpu_scan_has_avx512();
+    const int G = wide ? G512 : G256, RB = wide ? ROWS512 : ROWS256;
     const int64_t cap = 2 * k + 16;
-    const int64_t nq4 = (nq + 3) & ~(int64_t)3;
+    const int64_t ngroups = (nq + G - 1) / G, nqp = ngroups * G;
 
-    /* queries padded to a multiple of 4 rows + their norms */
-    float *q = NULL, *xn = (float *)calloc((size_t)(nq4 ? nq4 : 1), sizeof(float));
-    if (posix_memalign((void **)&q, 64, (size_t)(nq4 ? nq4 : 4) * d * sizeof(float)) || !xn) return -1;
-    memset(q, 0, (size_t)(nq4 ? nq4 : 4) * d * sizeof(float));
-    memcpy(q, xq, (size_t)nq * d * sizeof(float));
-    if (metric == 1)
-        for (int64_t i = 0; i < nq; i++) xn[i] = dot_scalar(q + i * d, q + i * d, d);
+    /* queries transposed by group: qt[g][j][G], zero padded; their norms; the running thresholds */
+    float *qt = NULL, *xn = (float *)calloc((size_t)(nqp ? nqp : 1), sizeof(float));
+    if (posix_memalign((void **)&qt, 64, (size_t)(nqp ? nqp : G) * d * sizeof(float)) || !xn) return -1;
+    memset(qt, 0, (size_t)(nqp ? nqp : G) * d * sizeof(float));
+    for (int64_t i = 0; i < nq; i++) {
+        const float *src = xq + i * d;
+        float *dst = qt + (i / G) * (size_t)G * d + (i % G);
+        for (int32_t j = 0; j < d; j++) dst[(size_t)j * G] = src[j];
+        if (metric == 1) xn[i] = dot_scalar(src, src, d);
+    }
 
     qbuf_t *bufs = (qbuf_t *)calloc((size_t)threads * (nq ? nq : 1), sizeof(qbuf_t));
     int failed = bufs == NULL;
@@ -261,7 +231,9 @@ int cpu_scan_search(const float *xb, const float *yn, int64_t nb, const float *x
 #pragma omp single
         used_threads = nth;
         qbuf_t *mine = bufs ? bufs + (size_t)t * nq : NULL;
-        if (mine) {
+        float *thr = (float *)malloc((size_t)(nqp ? nqp : 1) * sizeof(float)); /* thr[q]: vector-loadable copy of mine[q].thr */
+        if (mine && thr) {
+            for (int64_t i = 0; i < nqp; i++) thr[i] = i < nq ? FLT_MAX : -FLT_MAX; /* padding queries admit nothing */
             for (int64_t i = 0; i < nq; i++) {
                 mine[i].c = (cand_t *)malloc((size_t)cap * sizeof(cand_t));
                 mine[i].cnt = 0;
@@ -271,41 +243,51 @@ int cpu_scan_search(const float *xb, const float *yn, int64_t nb, const float *x
                     failed = 1;
                 }
             }
+        } else {
+#pragma omp atomic write
+            failed = 1;
         }
 #pragma omp barrier
         if (!failed) {
             int64_t lo, hi;
             row_range(nb, nth, t, &lo, &hi);
-            float s[16];
-            for (int64_t r = lo; r < hi; r += 4) {
+            float sc[ROWS512 * G512] __attribute__((aligned(64)));
+            const float *y[ROWS512];
+            for (int64_t r = lo; r < hi; r += RB) {
                 /* a ragged last block re-reads the last row; its extra results are dropped */
-                const int64_t last = hi - 1;
-                const float *y0 = xb + r * d;
-                const float *y1 = xb + (r + 1 <= last ? r + 1 : last) * d;
-                const float *y2 = xb + (r + 2 <= last ? r + 2 : last) * d;
-                const float *y3 = xb + (r + 3 <= last ? r + 3 : last) * d;
-                const int rows = (int)(hi - r < 4 ? hi - r : 4);
-                for (int64_t qb = 0; qb < nq4; qb += 4) {
-                    dots(y0, y1, y2, y3, q + qb * d, d, d, s);
-                    for (int rr = 0; rr < rows; rr++)
-                        for (int qq = 0; qq < 4 && qb + qq < nq; qq++) {
-                            float ip = s[rr * 4 + qq], v;
+                const int rows = (int)(hi - r < RB ? hi - r : RB);
+                for (int i = 0; i < RB; i++) y[i] = xb + (r + (i < rows ? i : rows - 1)) * d;
+                for (int64_t g = 0; g < ngroups; g++) {
+                    if (wide) scores_avx512(y, qt + (size_t)g * G * d, d, sc);
+                    else scores_avx2(y, qt + (size_t)g * G * d, d, sc);
+                    const float *tg = thr + g * G;
+                    for (int rr = 0; rr < rows; rr++) {
+                        const float ynr = metric == 1 ? yn[r + rr] : 0.f;
+                        for (int qq = 0; qq < G; qq++) {
+                            float v;
                             if (metric == 0) {
-                                v = -ip;
+                                v = -sc[rr * G + qq];
                             } else {
-                                v = xn[qb + qq] + yn[r + rr] - 2.f * ip;
+                                v = xn[g * G + qq] + ynr - 2.f * sc[rr * G + qq];
                                 if (v < 0.f) v = 0.f;
                             }
-                            qbuf_t *b = &mine[qb + qq];
-                            if (v < b->thr || (v == b->thr && b->cnt < k)) {
-                                b->c[b->cnt].v = v;
-                                b->c[b->cnt].id = r + rr;
-                                if (++b->cnt == cap) qbuf_shrink(b, k);
+                            if (__builtin_expect(v <= tg[qq], 0)) {
+                                qbuf_t *b = &mine[g * G + qq];
+                                if (v < b->thr || b->cnt < k) {
+                                    b->c[b->cnt].v = v;
+                                    b->c[b->cnt].id = r + rr;
+                                    if (++b->cnt == cap) {
+                                        qbuf_shrink(b, k);
+                                        thr[g * G + qq] = b->thr;
+                                    }
+                                }
                             }
                         }
+                    }
                 }
             }
         }
+        free(thr);
     }
     /* merge: per query, all threads' candidates, best k */
     if (!failed) {
@@ -337,7 +319,7 @@ int cpu_scan_search(const float *xb, const float *yn, int64_t nb, const float *x
         for (size_t i = 0; i < (size_t)used_threads * nq; i++) free(bufs[i].c);
         free(bufs);
     }
-    free(q);
+    free(qt);
     free(xn);
     return failed ? -1 : 0;
 }
