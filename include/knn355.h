@@ -264,17 +264,21 @@ float knn_last_scan_ms(knn_handle h);
  * most max_n), each from a hipEvent pair recorded around the launch on the stream it
  * was launched on; -1 for a launch that has not finished.  Returns the count. */
 int32_t knn_scan_times(knn_handle h, float *out_ms, int32_t max_n);
-/* how the last search on this handle was seeded: seed_stride = 0 (no seed sample) or the
- * stride of the sample searched first; stat_rank = 0 (the sample's k-th score, a proven bound)
+/* how the last search on this handle was seeded: seed_stride = 0 (no seed sample), the
+ * stride of the sample searched first, or -r (tile-minimum seed: no sample pass, every chunk of the
+ * scan publishes the best key of each of its first r tiles and the k-th smallest published key
+ * is the bound); stat_rank = 0 (the sample's k-th score, a proven bound)
  * or j (statistical seed: the sample's j-th score, result verified); stat_redo = searches
  * repeated so far because a statistical threshold failed its verification; sample_rows =
  * rows scanned by the sample pass (the main scan kernel skips them) */
 int knn_last_seed_info(knn_handle h, int32_t *seed_stride, int32_t *stat_rank, int64_t *stat_redo,
                        int64_t *sample_rows);
 /* force a scan configuration: query_tile in {0(auto),32,64,128}; nchunks 0=auto;
- * flags: 8 = no seed sample, 16 = force the exact seed, 128 = force the statistical seed
+ * flags: 4 = never pair the workgroups of a one-query-tile launch (static chunks instead), 8 = no seed sample, 16 = force the exact seed, 128 = force the statistical seed
  * (synchronous entry points only), 512 = never use the statistical seed, 1024 = never use the
- * symmetric launch of a whole-index self-search */
+ * symmetric launch of a whole-index self-search, 2048 = never use the tile-minimum seed (a streaming
+ * search then runs its seed sample as a launch of its own), bits 12-13 = publication rounds of the
+ * tile-minimum seed (0 = the library's choice) */
 int knn_set_tuning(knn_handle h, int32_t query_tile, int32_t nchunks, int32_t flags);
 
 #ifdef __cplusplus

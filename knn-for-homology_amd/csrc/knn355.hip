@@ -202,6 +202,7 @@ __device__ __forceinline__ int next_pow2_dev(int n)
 // (dst may alias lst).  No LDS, no barriers: four waves of a workgroup select
 // for four different queries at once.
 //   *thr_ord receives T with count(hi <= T) >= k, a valid admission threshold.
+//   dst may be NULL: only T is wanted (the tile-minimum seed of the scan kernel).
 // Method: MSB-first binary search on the 32-bit score word ("largest P with
 // count(hi < P) <= k-1"), each probe one v_cmp + s_bcnt1 per register, started
 // below the bits all keys share and stopped as soon as a probe leaves between k
@@ -223,6 +224,12 @@ typedef const __attribute__((address_space(1))) uint64_t *gptr_u64; // explicit 
 struct LoadContig {
     const uint64_t *p;
     __device__ __forceinline__ uint64_t operator()(int idx) const { return ((gptr_u64)p)[idx]; }
+};
+// keys other workgroups of the SAME launch are still publishing (agent scope: served from memory, never from a
+// stale line of this XCD's L2)
+struct LoadAgent {
+    const uint64_t *p;
+    __device__ __forceinline__ uint64_t operator()(int idx) const { return __hip_atomic_load(p + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 };
 // element idx of the concatenation of lists l0.. of query q inside a [list][query][k] buffer
 struct LoadListMajor {
@@ -395,7 +402,7 @@ __device__ __attribute__((noinline)) int wave_select(LD load, int n, int k, int 
 #pragma unroll
         for (int r = 0; r < R; r++) {
             if (hi[r] < Tk) {
-                if (pos < kmax) dst[pos] = ((uint64_t)hi[r] << 32) | lo[r];
+                if (pos < kmax && dst) dst[pos] = ((uint64_t)hi[r] << 32) | lo[r];
                 pos++;
             }
         }
@@ -409,7 +416,7 @@ __device__ __attribute__((noinline)) int wave_select(LD load, int n, int k, int 
 #pragma unroll
         for (int r = 0; r < R; r++) {
             if (hi[r] < Tlt || (hi[r] == T && lo[r] <= Q)) {
-                if (pos < kmax) dst[pos] = ((uint64_t)hi[r] << 32) | lo[r];
+                if (pos < kmax && dst) dst[pos] = ((uint64_t)hi[r] << 32) | lo[r];
                 pos++;
             }
         }
@@ -445,6 +452,38 @@ __device__ __forceinline__ int wave_select_dispatch_max(int R, LD load, int n, i
     }
 }
 
+// Keeps the keys of a list whose score word is <= T (packed to the front, in place), one wave, registers only.
+// Used at the end of a chunk of a tile-minimum-seeded scan: the first tiles were appended before any bound existed,
+// by now the shared threshold is tight and a compare does what a selection would.
+template <int R>
+__device__ __attribute__((noinline)) int wave_filter(uint64_t *lst, int n, uint32_t T, int lane)
+{
+    n = __builtin_amdgcn_readfirstlane(n);
+    T = __builtin_amdgcn_readfirstlane(T);
+    uint64_t key[R];
+    int mine = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int idx = r * 64 + lane;
+        key[r] = idx < n ? ((gptr_u64)lst)[idx] : KEY_PAD;
+        if ((r & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) mine += (key[r] != KEY_PAD && (uint32_t)(key[r] >> 32) <= T) ? 1 : 0;
+    const int incl = wave_inclusive_scan(mine);
+    int pos = incl - mine;
+#pragma unroll
+    for (int r = 0; r < R; r++)
+        if (key[r] != KEY_PAD && (uint32_t)(key[r] >> 32) <= T) lst[pos++] = key[r];
+    return __builtin_amdgcn_readlane(incl, 63);
+}
+__device__ __forceinline__ int wave_filter_dispatch(int R, uint64_t *lst, int n, uint32_t T, int lane)
+{
+    if (R <= 8) return wave_filter<8>(lst, n, T, lane);
+    if (R <= 16) return wave_filter<16>(lst, n, T, lane);
+    return wave_filter<32>(lst, n, T, lane);
+}
+
 // ---------------------------------------------------------------------------
 // scan kernel
 // ---------------------------------------------------------------------------
@@ -477,7 +516,25 @@ struct ScanParams {
     int kslot;         // most keys a chunk hands on per query: k + k/4
     const struct SymItem *sym_items; // symmetric all-vs-all launch: the work of each workgroup (see flat_scan_kernel)
     int *fail;         // symmetric launch: set when a candidate array overflows
+    // tile-minimum seed (streaming regime, see flat_scan_kernel): after each of its first pub_rounds tiles a workgroup
+    // publishes every query's best key of that tile; the k-th smallest published key bounds the global k-th
+    uint64_t *pub;     // [nqtiles*QT][pub_n], pub_n = pub_rounds * nchunks, KEY_PAD = not published yet; NULL: off
+    uint32_t *arrive;  // [nqtiles] publications so far
+    int pub_n, pub_rounds;
+    float *defer;      // [grid][QT * DT] the parked scores of every workgroup's first tile
+    // paired workgroups (one-query-tile launches): workgroups w and w + npairs share ONE range of tiles, w walks it from
+    // the front, w + npairs from the back; every tile is claimed with a ticket (see flat_scan_kernel)
+    uint32_t *pair_ctr; // [npairs] tickets handed out so far (starts at 2: the first tile of either side); NULL: off
+    int npairs;
+#ifdef KNN355_TRACE
+    unsigned long long *trace; // developer build: [grid][64] wall-clock stamps (100 MHz) of each workgroup's progress
+#endif
 };
+#ifdef KNN355_TRACE
+#define KNN_TRACE(slot) do { if (threadIdx.x == 0 && p.trace && (slot) < 64) p.trace[(size_t)blockIdx.x * 64 + (slot)] = wall_clock64(); } while (0)
+#else
+#define KNN_TRACE(slot) do { } while (0)
+#endif
 
 // Views: view row r of a launch with stride row_mul and block size B = 1 << vshift is database row
 // (r / B) * B * row_mul + r % B -- blocks of B consecutive rows, every row_mul-th block (row_mul = 1:
@@ -509,6 +566,7 @@ struct ListCtx {
     uint32_t *gthr;   // [QT] shared running thresholds of these queries
     int cap, k;
     int kslot;        // size of this workgroup's output slot per query (k + k/4)
+    bool prefilter;   // end of chunk: drop what the shared threshold has overtaken before any selection
 
     __device__ __forceinline__ void init(int tid, int QT, int nthreads = 256)
     {
@@ -517,6 +575,7 @@ struct ListCtx {
             s_cnt[i] = 0;
         }
         if (tid == 0) *s_need = 0;
+        prefilter = false;
     }
     __device__ __forceinline__ float threshold(int ql) const
     {
@@ -560,6 +619,20 @@ __device__ __forceinline__ void lists_compact(ListCtx &L, char *smem, int tile_r
                     continue;
                 }
                 kmax = L.kslot;
+                if (L.prefilter) {
+                    const int m = wave_filter_dispatch(R, lst, n, f2ord(L.threshold(ql)), lane);
+                    if (m <= L.kslot) {
+                        if (lane == 0) L.s_cnt[ql] = m;
+                        continue;
+                    }
+                    const int cnt2 = wave_select_dispatch(R, LoadContig{lst}, m, L.k, kmax, lane, &T, lst);
+                    if (lane == 0) {
+                        L.s_cnt[ql] = cnt2;
+                        L.s_thr[ql] = ord2f(T);
+                        atomicMin(&L.gthr[ql], T);
+                    }
+                    continue;
+                }
             }
             const int cnt = wave_select_dispatch(R, LoadContig{lst}, n, L.k, kmax, lane, &T, lst);
             if (lane == 0) {
@@ -697,15 +770,31 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
     } else {
         qtile = blockIdx.x % p.nqtiles;
         chunk = blockIdx.x / p.nqtiles;
+        if (NTDB && p.pair_ctr) chunk = blockIdx.x % p.npairs; // (one query tile: blockIdx.x is the workgroup of the pair)
         c_lo = ((int64_t)chunk * p.tiles_base + min(chunk, p.tiles_rem)) * DT;
         c_hi = min(p.nb, c_lo + (int64_t)(p.tiles_base + (chunk < p.tiles_rem ? 1 : 0)) * DT);
     }
+    // Paired walk (NTDB launches = one query tile = the HBM-bound streaming regime).  Two workgroups per CU is what the
+    // LDS holds, and the two residents of a CU do not progress alike: the older one wins the arbitration and finished its
+    // 10 tiles of a 1.25 M-row shard one tile time before the younger one, which then ran its last tile alone (per-
+    // workgroup stamps: every CU's later workgroup ended at 1000 us, its earlier one at 907; 23 CUs had one workgroup and
+    // idled from 600 us on).  So a launch has exactly 2 x CUs workgroups, workgroups w and w + npairs (dispatched one
+    // round apart: an older and a younger resident) share ONE range of tiles, w takes tiles from the front, w + npairs
+    // from the back, and each tile is claimed with a ticket from the pair's counter: both stay busy until the range is
+    // used up, whatever their speeds.  Each side still walks contiguous rows (translations and DRAM pages stay warm --
+    // pulling single tiles from one global counter cost 2.5-10 %).  The ticket of the NEXT tile is drawn at the start of
+    // the current one: its latency hides behind the K loop.
+    const bool paired = NTDB && !SYM && p.pair_ctr != nullptr;
+    const int side = paired ? (int)(blockIdx.x / p.npairs) : 0;
+    const int ntl = (int)((c_hi - c_lo + DT - 1) / DT); // tiles of this chunk / of the pair's range
+    int *s_next = nullptr;
     const int64_t q0 = (int64_t)qtile * QT;
     const int KT = p.dp / 32;
     ListCtx L;
     L.s_thr = (float *)(smem + lds_main);
     L.s_cnt = (int *)(L.s_thr + QT);
     L.s_need = L.s_cnt + QT;
+    s_next = L.s_need + 1;                 // the ticket drawn for this workgroup's next tile (paired walk)
     int *s_base = L.s_need + 4;            // [QT] first slot of each query's survivors in its compact array
     float *s_yn = (float *)(s_base + QT);  // [DT] squared norms of the current tile's rows (L2 only)
     float *s_thr2 = s_yn + DT;             // SYM: [DT] thresholds of the tile's rows taken as queries
@@ -717,6 +806,19 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
     L.k = p.k;
     L.kslot = p.kslot;
     L.init(tid, QT);
+    // Tile-minimum seed (plain fp32 launches of the streaming regime; the host turns it on when the launch has a few
+    // times k chunks).  No sample pass in front of the launch: every workgroup filters its first tile against nothing,
+    // publishes each query's BEST key of that tile, and the k-th smallest of all keys published so far -- keys of k
+    // different rows -- is an upper bound of the global k-th: one wave of the publishing workgroup works it out for one
+    // query (wave_select over <= 2048 published keys) and lowers the shared threshold.  With c chunks of DT-row tiles
+    // the bound sits near the k / (c DT) quantile (1.25 M rows, k = 100: ~1100 candidates per query for the whole
+    // launch; the sample pass it replaces cost 90 us in front of a 0.85 ms scan and admitted 12 k).  A publication that
+    // a reader does not see yet reads as KEY_PAD: the bound is then looser, never wrong.
+    constexpr bool CAN_PUB = !SYM && !BF16 && QT <= 64;
+    uint64_t *s_pub = (uint64_t *)s_thr2; // [QT] (a plain launch has no s_thr2)
+    const bool pub_on = CAN_PUB && p.pub != nullptr;
+    L.prefilter = pub_on;
+    if (pub_on && tid < QT) s_pub[tid] = KEY_PAD;
     __syncthreads();
     // per-lane staging bookkeeping: instruction ii covers combined rows 8*ii..8*ii+7
     const float *srcp[NI];
@@ -745,7 +847,19 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
     }
     const int swz = (li >> 1) & 7;
 
-    for (int64_t row0 = c_lo; row0 < c_hi; row0 += DT) {
+    int tile_idx = 0; // tiles this workgroup has walked
+    int ticket = side; // (unpaired: the tile's position in the chunk)
+    KNN_TRACE(0);
+#ifdef KNN355_TRACE
+    if (threadIdx.x == 0 && p.trace) // where this workgroup runs: HW_ID (hwreg 4) and XCC_ID (hwreg 20)
+        p.trace[(size_t)blockIdx.x * 64 + 62] = ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32) | (unsigned)__builtin_amdgcn_s_getreg(0xF804);
+#endif
+    int64_t first_row0 = c_lo;
+    while (ticket < ntl) {
+        const int64_t row0 = c_lo + (int64_t)(paired ? (side == 0 ? tile_idx : ntl - 1 - tile_idx) : ticket) * DT;
+        if (tile_idx == 0) first_row0 = row0;
+        int next_ticket = ticket + 1;
+        if (paired && tid == 0) next_ticket = (int)__hip_atomic_fetch_add(&p.pair_ctr[chunk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         f32x16 acc[TM][TN];
 #pragma unroll
         for (int a = 0; a < TM; a++)
@@ -861,34 +975,131 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
         }
         __syncthreads();
         compute(((KT - 1) & 1) ? stage1 : stage0, no_dma, nd_none{});
+        KNN_TRACE(1 + 2 * tile_idx);
+        if (paired && tid == 0) *s_next = next_ticket; // (read by everyone behind the barrier that ends the epilogue)
+
+        // score of accumulator register r of MFMA tile (a, b) -- "smaller is better"
+        auto score_of = [&](int a, int b, int r, float xnq) -> float {
+            if constexpr (L2) {
+                const float ynr = s_yn[(wm * TM + a) * 32 + 4 * lh + (r & 3) + 8 * (r >> 2)];
+                const float v = __builtin_fmaf(-2.0f, acc[a][b][r], xnq + ynr);
+                return v < 0.0f ? 0.0f : v;
+            } else {
+                return -acc[a][b][r];
+            }
+        };
+        // threshold filter + append of one tile's scores (getv(a, b, r, xnq): from the accumulators, or read back from
+        // the deferred first tile)
+        auto filter_tile = [&](int64_t trow0, auto &&getv) {
+#pragma unroll
+            for (int b = 0; b < TN; b++) {
+                const int ql = (wn * TN + b) * 32 + li;
+                const int64_t q = q0 + ql;
+                const bool qok = q < p.nq;
+                const float thr = L.threshold(ql);
+                float xnq = 0.0f;
+                if constexpr (L2) xnq = p.xn[qok ? q : 0];
+#pragma unroll
+                for (int a = 0; a < TM; a++) {
+                    const int64_t rbase = trow0 + (wm * TM + a) * 32 + 4 * lh;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
+                        const float v = getv(a, b, r, xnq);
+                        if (v <= thr && row < c_hi && qok && !(p.skip_mask >= 0 && ((int)(row >> p.vshift) & p.skip_mask) == 0))
+                            L.append(ql, v, p.id_base + (uint32_t)view_row(row, p.row_mul, p.vshift), DT);
+                    }
+                }
+            }
+        };
+        constexpr int NV4 = TM * TN * 4; // 16-byte pieces of a lane's scores of one tile
+        bool deferred = false;
+        if constexpr (CAN_PUB) {
+            if (pub_on && tile_idx < p.pub_rounds) {
+                // ---- tile-minimum seed: publish this tile's best key per query BEFORE the tile is filtered ----
+                // lane minimum over its 16 TM TN scores, the other lane half, then the waves through LDS.  The FIRST tile
+                // has nothing to filter with yet (unfiltered it would append all of its 256 x QT scores: 32 MB of list
+                // writes per launch on a 1.25 M-row shard, +110 us; waiting for the bound costs every workgroup the spread
+                // of the arrivals): its scores are parked in global memory (32 KB per workgroup, one coalesced store per
+                // 4 accumulator registers) and filtered behind the second tile, when the bound has long been there.
+                float4 *park = (float4 *)p.defer + (size_t)blockIdx.x * NV4 * 256 + tid;
+#pragma unroll
+                for (int b = 0; b < TN; b++) {
+                    const int ql = (wn * TN + b) * 32 + li;
+                    const int64_t q = q0 + ql;
+                    float xnq = 0.0f;
+                    if constexpr (L2) xnq = p.xn[q < p.nq ? q : 0];
+                    uint64_t best = KEY_PAD;
+#pragma unroll
+                    for (int a = 0; a < TM; a++) {
+                        const int64_t rbase = row0 + (wm * TM + a) * 32 + 4 * lh;
+                        float vs[16];
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
+                            const float v = score_of(a, b, r, xnq) + 0.0f;
+                            vs[r] = v;
+                            // (a key that is published must be one the filter would append: a real row of this chunk, finite)
+                            if (v < INFINITY && row < c_hi && !(p.skip_mask >= 0 && ((int)(row >> p.vshift) & p.skip_mask) == 0)) {
+                                const uint64_t key = ((uint64_t)f2ord(v) << 32) | (p.id_base + (uint32_t)view_row(row, p.row_mul, p.vshift));
+                                best = key < best ? key : best;
+                            }
+                        }
+                        if (tile_idx == 0) {
+#pragma unroll
+                            for (int j = 0; j < 4; j++)
+                                park[(size_t)((b * TM + a) * 4 + j) * 256] = make_float4(vs[4 * j], vs[4 * j + 1], vs[4 * j + 2], vs[4 * j + 3]);
+                        }
+                    }
+                    const uint32_t ohi = (uint32_t)__shfl_xor((int)(uint32_t)(best >> 32), 32);
+                    const uint32_t olo = (uint32_t)__shfl_xor((int)(uint32_t)best, 32);
+                    const uint64_t other = ((uint64_t)ohi << 32) | olo;
+                    best = other < best ? other : best;
+                    if (lh == 0 && q < p.nq) atomicMin((unsigned long long *)&s_pub[ql], (unsigned long long)best);
+                }
+                deferred = tile_idx == 0;
+                __syncthreads();
+                if (wave == 0) {
+                    if (lane < QT) {
+                        if (q0 + lane < p.nq)
+                            __hip_atomic_store(&p.pub[(size_t)(q0 + lane) * p.pub_n + (size_t)tile_idx * p.nchunks + (paired ? (int)blockIdx.x : chunk)], s_pub[lane],
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        s_pub[lane] = KEY_PAD; // (the next round's minima land after the next K loop's barriers)
+                    }
+                    // No fence, relaxed counter: a release at agent scope writes back this XCD's whole L2 and an acquire
+                    // invalidates it (measured: +120 us per launch).  Nothing here needs the order: a publication a reader
+                    // misses reads as KEY_PAD.
+                    int a = 0;
+                    if (lane == 0) a = (int)__hip_atomic_fetch_add(&p.arrive[qtile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    a = __builtin_amdgcn_readfirstlane(a);
+                    // arrivals take the queries in turn: from the (k + QT)-th on every query has a bound, the last QT
+                    // arrivals of a round see (almost) every publication
+                    const int ql = a % QT;
+                    if (q0 + ql < p.nq && a + 1 >= p.k) {
+                        uint32_t T = 0xFFFFFFFFu;
+                        const int kmax = p.k + max(p.k >> 2, 32);
+                        wave_select_dispatch((p.pub_n + 63) >> 6, LoadAgent{p.pub + (size_t)(q0 + ql) * p.pub_n}, p.pub_n, p.k, kmax, lane, &T,
+                                             (uint64_t *)nullptr);
+                        if (lane == 0 && T != 0xFFFFFFFFu) atomicMin(&L.gthr[ql], T);
+                    }
+                }
+            }
+        }
 
         // ---- epilogue: threshold filter + append ----
+        if (!deferred) filter_tile(row0, score_of);
+        if constexpr (CAN_PUB) {
+            if (pub_on && (tile_idx == 1 || (deferred && (paired ? *s_next >= ntl : ticket + 1 >= ntl)))) {
+                // the parked first tile (every lane reads back what it stored itself); a chunk of a single tile filters
+                // it on the spot
+                const float4 *park = (const float4 *)p.defer + (size_t)blockIdx.x * NV4 * 256 + tid;
+                float4 pv[NV4];
 #pragma unroll
-        for (int b = 0; b < TN; b++) {
-            const int ql = (wn * TN + b) * 32 + li;
-            const int64_t q = q0 + ql;
-            const bool qok = q < p.nq;
-            const float thr = L.threshold(ql);
-            float xnq = 0.0f;
-            if constexpr (L2) xnq = p.xn[qok ? q : 0];
-#pragma unroll
-            for (int a = 0; a < TM; a++) {
-                const int64_t rbase = row0 + (wm * TM + a) * 32 + 4 * lh;
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
-                    float v;
-                    if constexpr (L2) {
-                        float ynr = s_yn[(wm * TM + a) * 32 + 4 * lh + (r & 3) + 8 * (r >> 2)];
-                        float t = xnq + ynr;
-                        v = __builtin_fmaf(-2.0f, acc[a][b][r], t);
-                        v = v < 0.0f ? 0.0f : v;
-                    } else {
-                        v = -acc[a][b][r];
-                    }
-                    if (v <= thr && row < c_hi && qok && !(p.skip_mask >= 0 && ((int)(row >> p.vshift) & p.skip_mask) == 0))
-                        L.append(ql, v, p.id_base + (uint32_t)view_row(row, p.row_mul, p.vshift), DT);
-                }
+                for (int j = 0; j < NV4; j++) pv[j] = park[(size_t)j * 256];
+                filter_tile(first_row0, [&](int a, int b, int r, float) -> float {
+                    const float4 w = pv[(b * TM + a) * 4 + (r >> 2)];
+                    return (r & 3) == 0 ? w.x : ((r & 3) == 1 ? w.y : ((r & 3) == 2 ? w.z : w.w));
+                });
             }
         }
         if constexpr (SYM) {
@@ -969,12 +1180,16 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
             }
         }
         __syncthreads();
-
         // ---- compaction of lists that could overflow on the next tile ----
-        const bool last_tile = row0 + DT >= c_hi;
+        if (paired) next_ticket = *s_next;
+        const bool last_tile = next_ticket >= ntl;
         if (*L.s_need || last_tile) lists_compact<QT>(L, smem, DT, last_tile, tid);
+        KNN_TRACE(2 + 2 * tile_idx);
+        ticket = next_ticket;
+        tile_idx++;
     }
     lists_flush<QT>(L, s_base, q0, p.nq, p.qlist, p.qcnt, p.qcap, tid, SYM ? p.fail : nullptr);
+    KNN_TRACE(63);
 }
 
 // ---------------------------------------------------------------------------
@@ -1296,9 +1511,17 @@ __global__ __launch_bounds__(NT) void select_topk_kernel(SelectParams p)
 // (re)initialises a level's per-query state in one launch: running thresholds "no bound", empty candidate
 // arrays, no verification bound
 __global__ void init_level_kernel(uint32_t *__restrict__ gthr, int64_t nslots, uint32_t *__restrict__ qcnt,
-                                  uint32_t *__restrict__ qthr, int64_t nq, int *__restrict__ flag)
+                                  uint32_t *__restrict__ qthr, int64_t nq, int *__restrict__ flag,
+                                  uint64_t *__restrict__ pub = nullptr, int64_t npub = 0, uint32_t *__restrict__ arrive = nullptr,
+                                  int64_t narrive = 0, uint32_t *__restrict__ pair_ctr = nullptr, int64_t npairs = 0)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pair_ctr) // paired walk: tickets 0 and 1 are the two workgroups' first tiles
+        for (int64_t j = i; j < npairs; j += (int64_t)gridDim.x * blockDim.x) pair_ctr[j] = 2u;
+    if (pub) { // tile-minimum seed: nothing published yet
+        for (int64_t j = i; j < npub; j += (int64_t)gridDim.x * blockDim.x) pub[j] = KEY_PAD;
+        if (i < narrive) arrive[i] = 0u;
+    }
     if (gthr && i < nslots) gthr[i] = 0xFFFFFFFFu;
     if (qcnt && i < nq) {
         qcnt[i] = 0u;
@@ -1455,10 +1678,24 @@ struct DevBuf {
     }
 };
 
+#ifdef KNN355_TRACE
+static DevBuf g_trace_buf;
+static int g_trace_grid = 0;
+// developer build only: the stamps of the last top-level scan launch, [grid][64]; returns the grid
+extern "C" int knn_dev_trace_read(unsigned long long *out, int max_wgs)
+{
+    const int n = std::min(max_wgs, g_trace_grid);
+    if (n > 0 && hipMemcpy(out, g_trace_buf.p, (size_t)n * 64 * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return g_trace_grid;
+}
+#endif
+
 // per seed-recursion level: compact candidate arrays [nq][qcap] + their fill, the shared running
 // thresholds and the verification bounds of a statistically seeded pass
 struct LevelBufs {
     DevBuf qlist, qcnt, gthr, qthr;
+    DevBuf pub, arrive; // tile-minimum seed: published keys [nslots][rounds * nchunks], arrival counters [nqtiles]
+    DevBuf pair_ctr;    // paired walk: ticket counter of every pair of workgroups
 };
 
 // HIP streams are recycled: creating one costs a third of a millisecond, and the reference's scripts build a fresh
@@ -1515,6 +1752,7 @@ struct knn_index_s {
     DevBuf ws_D1, ws_I1, ws_tmp3; // second set for the pipelined host search
     DevBuf ws_flag;               // [0]: a statistically seeded search failed its verification
     DevBuf ws_sym;                // work table of a symmetric all-vs-all launch
+    DevBuf ws_defer;              // tile-minimum seed: the parked first-tile scores of every workgroup
     int64_t sym_searches = 0;     // self-searches served by the symmetric path
     static const int MAX_LEVELS = 8;
     LevelBufs ws_level[MAX_LEVELS]; // per seed-recursion level
@@ -1524,6 +1762,7 @@ struct knn_index_s {
     int *flag_host = nullptr;     // pinned: [slot] copy of ws_flag behind each batch of a host search
     // tuning + introspection
     int force_qt = 0, force_chunks = 0, flags = 0;
+    int pub_rounds_force = 0; // tile-minimum seed: rounds of publications (0: the host's choice)
     std::string last_kernel;
     int last_qt = 0, last_dt = 0, last_chunks = 0, last_grid = 0;
     float last_ms = 0.f;
@@ -1654,6 +1893,7 @@ extern "C" int knn_flat_view(knn_handle parent, knn_handle *out)
     HIP_TRY(hipSetDevice(parent->device));
     knn_index_s *h = new knn_index_s();
     h->flags = parent->flags;
+    h->pub_rounds_force = parent->pub_rounds_force;
     h->force_qt = parent->force_qt;
     h->force_chunks = parent->force_chunks;
     h->d = parent->d;
@@ -1704,13 +1944,16 @@ extern "C" void knn_free(knn_handle h)
         if (h->stream) (void)hipStreamSynchronize(h->stream);
         if (!h->is_view && h->xb) (void)hipDeviceSynchronize(); // a view's stream may still be scanning these rows
         free_index_buffers(h);
-        DevBuf *bufs[] = {&h->xb16, &h->ws_q16, &h->ws_sym, &h->ws_flag, &h->ws_q, &h->ws_qn, &h->ws_lists, &h->ws_D, &h->ws_I, &h->ws_tmp, &h->ws_tmp2, &h->ws_D1, &h->ws_I1, &h->ws_tmp3};
+        DevBuf *bufs[] = {&h->xb16, &h->ws_q16, &h->ws_sym, &h->ws_defer, &h->ws_flag, &h->ws_q, &h->ws_qn, &h->ws_lists, &h->ws_D, &h->ws_I, &h->ws_tmp, &h->ws_tmp2, &h->ws_D1, &h->ws_I1, &h->ws_tmp3};
         for (DevBuf *b : bufs) b->release();
         for (LevelBufs &b : h->ws_level) {
             b.qlist.release();
             b.qcnt.release();
             b.gthr.release();
             b.qthr.release();
+            b.pub.release();
+            b.arrive.release();
+            b.pair_ctr.release();
         }
         for (int i = 0; i < knn_index_s::RING; i++) {
             if (h->ring0[i]) (void)hipEventDestroy(h->ring0[i]);
@@ -1968,9 +2211,13 @@ static int launch_select(SelectParams sp, hipStream_t s, DevBuf *tmp = nullptr)
         else if (nmax <= 256 * 32) kern = select_topk_kernel<32, 256, true>;
         else { kern = select_topk_kernel<32, 1024, true>; nt = 1024; }
     } else {
-        if (nmax <= 256 * 4) kern = select_topk_kernel<4, 256, false>;
-        else if (nmax <= 256 * 16) kern = select_topk_kernel<16, 256, false>;
-        else if (nmax <= 256 * 32) kern = select_topk_kernel<32, 256, false>;
+        // (by the EXPECTED count when the arrays carry their own: the compact arrays of a seeded scan are sized for the worst
+        // case of every chunk -- 64 k slots per query on a 1.25 M-row shard -- and hold 1-2 k keys; the 1024-thread build
+        // took 32-36 us for them, its probes are workgroup-wide reductions over 16 waves)
+        const int nsel = sp.cnt ? nexp : nmax;
+        if (nsel <= 256 * 4) kern = select_topk_kernel<4, 256, false>;
+        else if (nsel <= 256 * 16) kern = select_topk_kernel<16, 256, false>;
+        else if (nsel <= 256 * 32) kern = select_topk_kernel<32, 256, false>;
         else { kern = select_topk_kernel<32, 1024, false>; nt = 1024; }
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)sp.nq), dim3(nt), lds, s, sp);
@@ -1980,6 +2227,7 @@ static int launch_select(SelectParams sp, hipStream_t s, DevBuf *tmp = nullptr)
 
 struct ScanPlan {
     int qt, dt, nqtiles, nchunks, cap, grid;
+    int npairs; // > 0: paired walk -- grid = nchunks = 2 npairs workgroups, tiles_base / tiles_rem split the tiles over the PAIRS
     int64_t chunk_rows;
     int tiles_base, tiles_rem;
     size_t lds;
@@ -2004,7 +2252,7 @@ static int launch_scan_cfg(const knn_index_s *h, const ScanParams &p, const Scan
     return 0;
 }
 
-static void make_plan(const knn_index_s *h, int64_t nb, int64_t nq, int k, bool seeded, ScanPlan &pl)
+static void make_plan(const knn_index_s *h, int64_t nb, int64_t nq, int k, bool seeded, ScanPlan &pl, bool allow_pairs = false)
 {
     int qt = h->force_qt;
     if (qt != 32 && qt != 64 && qt != 128) qt = nq <= 32 ? 32 : (nq <= 64 ? 64 : 128);
@@ -2016,6 +2264,19 @@ static void make_plan(const knn_index_s *h, int64_t nb, int64_t nq, int k, bool 
     if (pl.cap < 512) pl.cap = 512;
     if (k <= KNN_WAVE_SELECT_MAX_K) pl.cap = std::min(pl.cap, 2048); // register select: <= 32 keys per lane
     const int64_t ntiles = (nb + pl.dt - 1) / pl.dt;
+    pl.npairs = 0;
+    if (allow_pairs && pl.nqtiles == 1 && h->force_chunks <= 0 && !(h->flags & 4) && ntiles >= 8 * (int64_t)std::max(1, h->num_cus)) {
+        // one query tile, plenty of tiles: two workgroups per CU, paired (see flat_scan_kernel): each pair shares a
+        // contiguous range of ~ ntiles / CUs tiles
+        pl.npairs = std::max(1, h->num_cus);
+        pl.nchunks = 2 * pl.npairs;
+        pl.grid = pl.nchunks;
+        pl.tiles_base = (int)(ntiles / pl.npairs);
+        pl.tiles_rem = (int)(ntiles % pl.npairs);
+        pl.chunk_rows = (int64_t)(pl.tiles_base + (pl.tiles_rem ? 1 : 0)) * pl.dt;
+        pl.lds = std::max((size_t)2 * (pl.dt + pl.qt) * 128, (size_t)pl.cap * 8) + (size_t)qt * 12 + 16 + (size_t)pl.dt * 4 + (size_t)qt * 8;
+        return;
+    }
     int64_t want = h->force_chunks > 0 ? h->force_chunks : (1024 + pl.nqtiles - 1) / pl.nqtiles;
     // an unseeded chunk should see enough rows to amortise its threshold warm-up; a seeded pass
     // starts with good thresholds and a tiny view (a seed sample) just wants parallelism
@@ -2052,7 +2313,7 @@ static void make_plan(const knn_index_s *h, int64_t nb, int64_t nq, int k, bool 
     pl.tiles_rem = (int)(ntiles % pl.nchunks);
     pl.chunk_rows = (int64_t)(pl.tiles_base + (pl.tiles_rem ? 1 : 0)) * pl.dt; // (the longest chunk)
     pl.grid = pl.nqtiles * pl.nchunks;
-    pl.lds = std::max((size_t)2 * (pl.dt + pl.qt) * 128, (size_t)pl.cap * 8) + (size_t)qt * 12 + 16 + (size_t)pl.dt * 4;
+    pl.lds = std::max((size_t)2 * (pl.dt + pl.qt) * 128, (size_t)pl.cap * 8) + (size_t)qt * 12 + 16 + (size_t)pl.dt * 4 + (size_t)qt * 8; // (+ s_pub)
 }
 
 // Seed stride of a view with nb rows: a power of two s such that the sample (every s-th 8-row block)
@@ -2114,7 +2375,8 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
 {
     const int64_t nb = view_rows(h->ntotal, row_mul, vshift);
     ScanPlan pl;
-    make_plan(h, nb, nq, k, true, pl);
+    const bool allow_pairs = !h->approx16; // (the bf16 build has no one-query-tile streaming case worth pairing)
+    make_plan(h, nb, nq, k, true, pl, allow_pairs);
     if (level >= knn_index_s::MAX_LEVELS) return set_err(KNN_ERR_INVALID, "search: seed recursion too deep");
     // Exact seeding pays when the sample that gives every chunk a tight threshold (about two chunks'
     // worth of rows, at least 64 k) is a small fraction of the view: the streaming regime (few
@@ -2154,7 +2416,25 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
             }
         }
     }
-    if (!sstride) make_plan(h, nb, nq, k, level > 0, pl); // a seed sample is small: parallelism over warm-up
+    // Tile-minimum seed (see flat_scan_kernel): where the exact seed would run a sample pass first, a launch with enough
+    // chunks seeds itself -- each chunk publishes its first tiles' best key per query, the k-th smallest published key
+    // is the bound.  Needs: the 32- or 64-query tile, plain fp32 rows, a few times k publications that fit one wave's
+    // registers (<= 2048), chunks long enough that an unfiltered first tile is noise.  flags & 2048: never.
+    int pub_rounds = 0;
+    if (seed && !(h->flags & (16 | 2048)) && !h->approx16 && pl.qt <= 64 && pl.cap >= 2 * pl.dt && pl.tiles_base >= (pl.npairs ? 8 : 4)) {
+        for (int r = 2; r >= 1; r--) // (one round if it gives enough publications)
+            if ((int64_t)r * pl.nchunks <= 2048 && (int64_t)r * pl.nchunks >= 2 * (int64_t)k + 64 && r < pl.tiles_base) pub_rounds = r;
+        if (h->pub_rounds_force > 0 && (int64_t)h->pub_rounds_force * pl.nchunks <= 2048 && h->pub_rounds_force < pl.tiles_base &&
+            (int64_t)h->pub_rounds_force * pl.nchunks >= (int64_t)k + 32)
+            pub_rounds = h->pub_rounds_force;
+    }
+    if (pub_rounds) {
+        sstride = 0;
+        // the bound sits near the k / (publications x tile rows) quantile; the first tile(s) of every chunk are filtered
+        // again at the end of the chunk
+        expect_n = 2.0 * (double)k * (double)nb / ((double)pub_rounds * pl.nchunks * pl.dt) + 2.0 * k + 64;
+    }
+    if (!sstride && !pub_rounds) make_plan(h, nb, nq, k, level > 0, pl, allow_pairs && level == 0); // a seed sample is small: parallelism over warm-up
     // Most keys a chunk hands on per query.  Chunks of a single tile (a seed sample, a tiny database)
     // hand on ALL their candidates: cutting 32 lists of one tile down to 1.25 k at the end of the only
     // tile is serial work per workgroup that the final selection does anyway, one workgroup per query.
@@ -2182,13 +2462,26 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
         if (rc) return rc;
     } else {
         const int64_t nn = std::max<int64_t>((int64_t)nslots, nq);
+        uint64_t *pub = nullptr;
+        uint32_t *arrive = nullptr;
+        const int64_t npub = (int64_t)nslots * pub_rounds * pl.nchunks;
+        if (pub_rounds) {
+            if (lb.pub.ensure((size_t)npub * 8) || lb.arrive.ensure((size_t)pl.nqtiles * 4)) return set_err(KNN_ERR_HIP, "search: out of device memory");
+            pub = (uint64_t *)lb.pub.p;
+            arrive = (uint32_t *)lb.arrive.p;
+        }
         // (the first launch of a search: it also clears the verification flag)
+        if (pl.npairs && lb.pair_ctr.ensure((size_t)pl.npairs * 4)) return set_err(KNN_ERR_HIP, "search: out of device memory");
         hipLaunchKernelGGL(init_level_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, s, gthr, (int64_t)nslots, qcnt, qthr, nq,
-                           reset_flag);
+                           reset_flag, pub, npub, arrive, (int64_t)pl.nqtiles, pl.npairs ? (uint32_t *)lb.pair_ctr.p : nullptr, (int64_t)pl.npairs);
         HIP_TRY(hipGetLastError());
     }
+    if (pl.npairs && sstride) { // (the sample's own search initialised this level: the pairs' ticket counters are left)
+        if (lb.pair_ctr.ensure((size_t)pl.npairs * 4)) return set_err(KNN_ERR_HIP, "search: out of device memory");
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)lb.pair_ctr.p, 2, (size_t)pl.npairs, s));
+    }
     if (h->ws_lists.ensure((size_t)pl.grid * pl.qt * pl.cap * 8)) return set_err(KNN_ERR_HIP, "search: out of device memory (candidate lists)");
-    ScanParams p;
+    ScanParams p = {};
     p.xb = h->xb; p.yn = h->yn; p.xq = q_dev; p.xn = xn;
     p.nb = nb; p.nq = nq; p.dp = h->dp; p.k = k; p.cap = pl.cap;
     if (h->approx16) { // bf16 rows and queries: a row is dp / 2 four-byte units
@@ -2203,7 +2496,25 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     p.vshift = sstride ? svshift : vshift;
     p.skip_mask = sstride ? sstride - 1 : -1;
     p.kslot = kslot;
+    p.pub = pub_rounds ? (uint64_t *)lb.pub.p : nullptr;
+    p.arrive = pub_rounds ? (uint32_t *)lb.arrive.p : nullptr;
+    p.pub_rounds = pub_rounds;
+    p.pub_n = pub_rounds * pl.nchunks;
+    p.pair_ctr = pl.npairs ? (uint32_t *)lb.pair_ctr.p : nullptr;
+    p.npairs = pl.npairs;
+    if (pub_rounds) {
+        if (h->ws_defer.ensure((size_t)pl.grid * pl.qt * pl.dt * 4)) return set_err(KNN_ERR_HIP, "search: out of device memory");
+        p.defer = (float *)h->ws_defer.p;
+    }
     const bool top = level == 0;
+#ifdef KNN355_TRACE
+    if (top) {
+        if (g_trace_buf.ensure((size_t)pl.grid * 64 * 8)) return set_err(KNN_ERR_HIP, "trace: out of device memory");
+        HIP_TRY(hipMemsetAsync(g_trace_buf.p, 0, (size_t)pl.grid * 64 * 8, s));
+        p.trace = (unsigned long long *)g_trace_buf.p;
+        g_trace_grid = pl.grid;
+    }
+#endif
     if (top) {
         const int slot = (int)(h->nlaunches % knn_index_s::RING);
         if (!h->ring0[slot]) {
@@ -2222,7 +2533,7 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     if (top) {
         HIP_TRY(hipEventRecord(h->ev1, s));
         h->last_kernel = pl.name; h->last_qt = pl.qt; h->last_dt = pl.dt; h->last_chunks = pl.nchunks; h->last_grid = pl.grid;
-        h->last_seed_stride = sstride;
+        h->last_seed_stride = pub_rounds ? -pub_rounds : sstride; // (negative: tile-minimum seed with that many rounds)
         h->last_seed_stat = seed_stat ? seed_j : 0;
         h->last_sample_rows = sstride ? view_rows(nb, sstride, p.vshift) : 0;
     }
@@ -2890,7 +3201,8 @@ extern "C" int knn_set_tuning(knn_handle h, int32_t query_tile, int32_t nchunks,
     std::lock_guard<std::mutex> lk(h->mu);
     h->force_qt = query_tile;
     h->force_chunks = nchunks;
-    h->flags = flags;
+    h->flags = flags & ~(3 << 12);
+    h->pub_rounds_force = (flags >> 12) & 3; // bits 12-13: publication rounds of the tile-minimum seed (0: the host's choice)
     return 0;
 }
 

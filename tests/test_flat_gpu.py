@@ -724,3 +724,49 @@ def test_device_search_of_many_queries_runs_in_blocks(gpu_faiss, oracle, metric)
     sample = np.concatenate([rng.choice(nq, 40, replace=False), [0, 16383, 16384, 32767, 32768, nq - 1]])
     Do, Io = oracle.flat_search(xb, xq[sample], k, metric)
     _assert_same(Dh[sample], Ih[sample], Do, Io)
+
+
+# ---- tile-minimum seed (streaming regime, round 3) ---------------------------------------------------------
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("nb,d,nq,k,rounds", [(600_000, 64, 32, 10, 0), (600_000, 32, 5, 10, 1), (700_001, 32, 40, 20, 2),
+                                              (900_000, 32, 1, 100, 0), (650_003, 40, 33, 1, 0)])
+def test_tile_minimum_seed_matches_oracle(gpu_faiss, oracle, metric, nb, d, nq, k, rounds):
+    """Few queries, many rows: the scan seeds itself (every chunk publishes the best key of its first tiles, the k-th
+    smallest published key bounds the global k-th) instead of running a sample pass first.  Same bits as the oracle and
+    as the sample-pass build (flags 2048), with duplicates and ties in the data."""
+    rng = np.random.default_rng(nb + k)
+    xb = rng.standard_normal((nb, d), dtype=np.float32)
+    xb[nb // 2: nb // 2 + 300] = xb[:300]          # exact duplicates: ties on the score word
+    xb[-50:] = 0.0                                  # and a block of identical rows at the ragged end
+    xq = np.concatenate([rng.standard_normal((max(nq - 2, 0), d), dtype=np.float32), xb[:min(2, nq)]])[:nq]
+    idx = gpu_faiss.IndexFlat(d, metric)
+    idx.add(xb)
+    idx.set_tuning(0, 0, rounds << 12)
+    D, I = idx.search(xq, k)
+    seed = idx.last_seed()
+    assert seed["stride"] < 0, f"expected the tile-minimum seed, got {seed} {idx.last_scan()}"
+    if rounds:
+        assert seed["stride"] == -rounds
+    Do, Io = oracle.flat_search(xb, xq, k, metric)
+    _assert_same(D, I, Do, Io)
+    idx.set_tuning(0, 0, 2048)
+    D2, I2 = idx.search(xq, k)
+    assert idx.last_seed()["stride"] >= 0
+    _assert_same(D2, I2, Do, Io)
+
+
+def test_tile_minimum_seed_with_adversarial_order(gpu_faiss, oracle):
+    """Rows sorted so that every chunk's first tile holds its WORST rows and the best rows of the whole database sit in
+    the last tiles of the last chunks: the published bound is loose, never wrong."""
+    rng = np.random.default_rng(5)
+    nb, d, nq, k = 640_000, 48, 32, 50
+    base = rng.standard_normal(d).astype(np.float32)
+    base /= np.linalg.norm(base)
+    scale = np.linspace(0.05, 2.0, nb, dtype=np.float32)
+    xb = (scale[:, None] * base[None, :] + 0.01 * rng.standard_normal((nb, d)).astype(np.float32)).astype(np.float32)
+    xq = (base[None, :] + 0.01 * rng.standard_normal((nq, d)).astype(np.float32)).astype(np.float32)
+    idx = gpu_faiss.IndexFlat(d, 0)
+    idx.add(xb)
+    D, I = idx.search(xq, k)
+    assert idx.last_seed()["stride"] < 0
+    _assert_same(D, I, *oracle.flat_search(xb, xq, k, 0))
