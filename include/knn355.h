@@ -274,7 +274,7 @@ int32_t knn_scan_times(knn_handle h, float *out_ms, int32_t max_n);
 int knn_last_seed_info(knn_handle h, int32_t *seed_stride, int32_t *stat_rank, int64_t *stat_redo,
                        int64_t *sample_rows);
 /* force a scan configuration: query_tile in {0(auto),32,64,128}; nchunks 0=auto;
- * flags: 4 = never pair the workgroups of a one-query-tile launch (static chunks instead), 8 = no seed sample, 16 = force the exact seed, 128 = force the statistical seed
+ * flags: 2 = no shared pool of tiles in a paired launch, 4 = never pair the workgroups of a one-query-tile launch (static chunks instead), 8 = no seed sample, 16 = force the exact seed, 128 = force the statistical seed
  * (synchronous entry points only), 512 = never use the statistical seed, 1024 = never use the
  * symmetric launch of a whole-index self-search, 2048 = never use the tile-minimum seed (a streaming
  * search then runs its seed sample as a launch of its own), bits 12-13 = publication rounds of the

@@ -525,7 +525,9 @@ struct ScanParams {
     // paired workgroups (one-query-tile launches): workgroups w and w + npairs share ONE range of tiles, w walks it from
     // the front, w + npairs from the back; every tile is claimed with a ticket (see flat_scan_kernel)
     uint32_t *pair_ctr; // [npairs] tickets handed out so far (starts at 2: the first tile of either side); NULL: off
+                        // pair_ctr[npairs]: tickets of the pool
     int npairs;
+    int pool_tiles;     // the last pool_tiles tiles of every pair's range belong to a pool shared by ALL workgroups
 #ifdef KNN355_TRACE
     unsigned long long *trace; // developer build: [grid][64] wall-clock stamps (100 MHz) of each workgroup's progress
 #endif
@@ -787,6 +789,11 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
     const bool paired = NTDB && !SYM && p.pair_ctr != nullptr;
     const int side = paired ? (int)(blockIdx.x / p.npairs) : 0;
     const int ntl = (int)((c_hi - c_lo + DT - 1) / DT); // tiles of this chunk / of the pair's range
+    // The pool: pairs do not progress alike either (per-XCD means of the workgroups' lives differed by 4 %, the slowest CU
+    // ended 6 % after the median one): the last pool_tiles tiles of every pair's range are nobody's -- a workgroup whose
+    // pair has used up its own tiles draws them, any pair's, from one global counter until they are gone.
+    const int n_own = paired ? ntl - p.pool_tiles : ntl;
+    const int tile_first = (int)(c_lo / DT);
     int *s_next = nullptr;
     const int64_t q0 = (int64_t)qtile * QT;
     const int KT = p.dp / 32;
@@ -848,18 +855,38 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
     const int swz = (li >> 1) & 7;
 
     int tile_idx = 0; // tiles this workgroup has walked
-    int ticket = side; // (unpaired: the tile's position in the chunk)
+    // the tile being walked / the one after it, as tile numbers of the view (-1: none)
+    int cur_tile = paired ? (side == 0 ? tile_first : tile_first + n_own - 1) : tile_first;
+    if (paired ? side >= n_own : ntl <= 0) cur_tile = -1;
+    int own_walked = 0;     // (thread 0) tiles drawn from the pair's own range, the first one included
+    bool in_pool = false;   // (thread 0) the pair's own tiles are gone
     KNN_TRACE(0);
 #ifdef KNN355_TRACE
     if (threadIdx.x == 0 && p.trace) // where this workgroup runs: HW_ID (hwreg 4) and XCC_ID (hwreg 20)
         p.trace[(size_t)blockIdx.x * 64 + 62] = ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32) | (unsigned)__builtin_amdgcn_s_getreg(0xF804);
 #endif
     int64_t first_row0 = c_lo;
-    while (ticket < ntl) {
-        const int64_t row0 = c_lo + (int64_t)(paired ? (side == 0 ? tile_idx : ntl - 1 - tile_idx) : ticket) * DT;
+    while (cur_tile >= 0) {
+        const int64_t row0 = (int64_t)cur_tile * DT;
         if (tile_idx == 0) first_row0 = row0;
-        int next_ticket = ticket + 1;
-        if (paired && tid == 0) next_ticket = (int)__hip_atomic_fetch_add(&p.pair_ctr[chunk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int next_tile = cur_tile + 1 < tile_first + ntl ? cur_tile + 1 : -1; // (unpaired: the chunk in order)
+        if (paired && tid == 0) {
+            next_tile = -1;
+            if (!in_pool) {
+                own_walked++;
+                const int t = (int)__hip_atomic_fetch_add(&p.pair_ctr[chunk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (t < n_own) next_tile = side == 0 ? tile_first + own_walked : tile_first + n_own - 1 - own_walked;
+                else in_pool = true;
+            }
+            if (in_pool && p.pool_tiles > 0) {
+                const int g = (int)__hip_atomic_fetch_add(&p.pair_ctr[p.npairs], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (g < p.npairs * p.pool_tiles) {
+                    // pool tile g: the (g / npairs)-th reserved tile of pair g % npairs
+                    const int pj = g % p.npairs, pi = g / p.npairs;
+                    next_tile = pj * p.tiles_base + min(pj, p.tiles_rem) + (p.tiles_base + (pj < p.tiles_rem ? 1 : 0)) - p.pool_tiles + pi;
+                }
+            }
+        }
         f32x16 acc[TM][TN];
 #pragma unroll
         for (int a = 0; a < TM; a++)
@@ -976,7 +1003,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
         __syncthreads();
         compute(((KT - 1) & 1) ? stage1 : stage0, no_dma, nd_none{});
         KNN_TRACE(1 + 2 * tile_idx);
-        if (paired && tid == 0) *s_next = next_ticket; // (read by everyone behind the barrier that ends the epilogue)
+        if (paired && tid == 0) *s_next = next_tile; // (read by everyone behind the barrier that ends the epilogue)
 
         // score of accumulator register r of MFMA tile (a, b) -- "smaller is better"
         auto score_of = [&](int a, int b, int r, float xnq) -> float {
@@ -1006,7 +1033,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
                     for (int r = 0; r < 16; r++) {
                         const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
                         const float v = getv(a, b, r, xnq);
-                        if (v <= thr && row < c_hi && qok && !(p.skip_mask >= 0 && ((int)(row >> p.vshift) & p.skip_mask) == 0))
+                        if (v <= thr && row < p.nb && qok && !(p.skip_mask >= 0 && ((int)(row >> p.vshift) & p.skip_mask) == 0))
                             L.append(ql, v, p.id_base + (uint32_t)view_row(row, p.row_mul, p.vshift), DT);
                     }
                 }
@@ -1040,7 +1067,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
                             const float v = score_of(a, b, r, xnq) + 0.0f;
                             vs[r] = v;
                             // (a key that is published must be one the filter would append: a real row of this chunk, finite)
-                            if (v < INFINITY && row < c_hi && !(p.skip_mask >= 0 && ((int)(row >> p.vshift) & p.skip_mask) == 0)) {
+                            if (v < INFINITY && row < p.nb && !(p.skip_mask >= 0 && ((int)(row >> p.vshift) & p.skip_mask) == 0)) {
                                 const uint64_t key = ((uint64_t)f2ord(v) << 32) | (p.id_base + (uint32_t)view_row(row, p.row_mul, p.vshift));
                                 best = key < best ? key : best;
                             }
@@ -1089,7 +1116,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
         // ---- epilogue: threshold filter + append ----
         if (!deferred) filter_tile(row0, score_of);
         if constexpr (CAN_PUB) {
-            if (pub_on && (tile_idx == 1 || (deferred && (paired ? *s_next >= ntl : ticket + 1 >= ntl)))) {
+            if (pub_on && (tile_idx == 1 || (deferred && (paired ? *s_next : next_tile) < 0))) {
                 // the parked first tile (every lane reads back what it stored itself); a chunk of a single tile filters
                 // it on the spot
                 const float4 *park = (const float4 *)p.defer + (size_t)blockIdx.x * NV4 * 256 + tid;
@@ -1181,11 +1208,11 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
         }
         __syncthreads();
         // ---- compaction of lists that could overflow on the next tile ----
-        if (paired) next_ticket = *s_next;
-        const bool last_tile = next_ticket >= ntl;
+        if (paired) next_tile = *s_next;
+        const bool last_tile = next_tile < 0;
         if (*L.s_need || last_tile) lists_compact<QT>(L, smem, DT, last_tile, tid);
         KNN_TRACE(2 + 2 * tile_idx);
-        ticket = next_ticket;
+        cur_tile = next_tile;
         tile_idx++;
     }
     lists_flush<QT>(L, s_base, q0, p.nq, p.qlist, p.qcnt, p.qcap, tid, SYM ? p.fail : nullptr);
@@ -1517,7 +1544,7 @@ __global__ void init_level_kernel(uint32_t *__restrict__ gthr, int64_t nslots, u
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pair_ctr) // paired walk: tickets 0 and 1 are the two workgroups' first tiles
-        for (int64_t j = i; j < npairs; j += (int64_t)gridDim.x * blockDim.x) pair_ctr[j] = 2u;
+        for (int64_t j = i; j <= npairs; j += (int64_t)gridDim.x * blockDim.x) pair_ctr[j] = j < npairs ? 2u : 0u; // ([npairs]: the pool's)
     if (pub) { // tile-minimum seed: nothing published yet
         for (int64_t j = i; j < npub; j += (int64_t)gridDim.x * blockDim.x) pub[j] = KEY_PAD;
         if (i < narrive) arrive[i] = 0u;
@@ -2471,14 +2498,15 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
             arrive = (uint32_t *)lb.arrive.p;
         }
         // (the first launch of a search: it also clears the verification flag)
-        if (pl.npairs && lb.pair_ctr.ensure((size_t)pl.npairs * 4)) return set_err(KNN_ERR_HIP, "search: out of device memory");
+        if (pl.npairs && lb.pair_ctr.ensure(((size_t)pl.npairs + 1) * 4)) return set_err(KNN_ERR_HIP, "search: out of device memory");
         hipLaunchKernelGGL(init_level_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, s, gthr, (int64_t)nslots, qcnt, qthr, nq,
                            reset_flag, pub, npub, arrive, (int64_t)pl.nqtiles, pl.npairs ? (uint32_t *)lb.pair_ctr.p : nullptr, (int64_t)pl.npairs);
         HIP_TRY(hipGetLastError());
     }
     if (pl.npairs && sstride) { // (the sample's own search initialised this level: the pairs' ticket counters are left)
-        if (lb.pair_ctr.ensure((size_t)pl.npairs * 4)) return set_err(KNN_ERR_HIP, "search: out of device memory");
+        if (lb.pair_ctr.ensure(((size_t)pl.npairs + 1) * 4)) return set_err(KNN_ERR_HIP, "search: out of device memory");
         HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)lb.pair_ctr.p, 2, (size_t)pl.npairs, s));
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)((uint32_t *)lb.pair_ctr.p + pl.npairs), 0, 1, s));
     }
     if (h->ws_lists.ensure((size_t)pl.grid * pl.qt * pl.cap * 8)) return set_err(KNN_ERR_HIP, "search: out of device memory (candidate lists)");
     ScanParams p = {};
@@ -2502,6 +2530,8 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     p.pub_n = pub_rounds * pl.nchunks;
     p.pair_ctr = pl.npairs ? (uint32_t *)lb.pair_ctr.p : nullptr;
     p.npairs = pl.npairs;
+    // the pool: about a tenth of every pair's tiles (none with flags & 2)
+    p.pool_tiles = pl.npairs && !(h->flags & 2) ? std::min(std::max(1, (pl.tiles_base + 5) / 10), pl.tiles_base / 4) : 0;
     if (pub_rounds) {
         if (h->ws_defer.ensure((size_t)pl.grid * pl.qt * pl.dt * 4)) return set_err(KNN_ERR_HIP, "search: out of device memory");
         p.defer = (float *)h->ws_defer.p;
