@@ -111,6 +111,13 @@ class IndexFlat(Index):
         return self.reconstruct_n(int(i), 1)[0]
 
     # -- knn355 extras (not in faiss) --
+    def reconstruct_into(self, out, i0=0):
+        """downloads rows [i0, i0 + len(out)) into the caller's float32 array"""
+        _check_matrix(out, self._d)
+        if not out.flags.writeable:
+            raise ValueError("reconstruct_into: array is read-only")
+        _lib.check(_lib.lib().knn_flat_reconstruct(self._h, int(i0), out.shape[0], out.ctypes.data))
+
     def search_self(self, k, row0=0, nrows=None):
         """``index.search(x, k)`` for x = the index's own rows [row0, row0+nrows): the all-vs-all
         the reference runs (cath/search.py:22-24), without uploading the queries again."""
@@ -348,8 +355,12 @@ def _write_flat(f, d, metric, rows):
     _w_vec(f, rows.reshape(-1), np.float32)
 
 
-def write_index(index, fname):
-    """faiss.write_index(index, str(path))"""
+def write_index(index, fname, rows=None):
+    """faiss.write_index(index, str(path)).  rows (not in faiss): the float32 rows the index holds, if the caller
+    still has them on the host -- saves downloading them again (pfam/proteins_search.py writes the index right
+    after adding the array it still holds)."""
+    if rows is not None and (rows.dtype != np.float32 or rows.shape != (index.ntotal, index.d) or not rows.flags.c_contiguous):
+        raise RuntimeError("write_index: rows must be the index's float32 [ntotal, d] contents")
     with open(str(fname), "wb") as f:
         if isinstance(index, IndexHNSWFlat):
             levels, offsets, nbrs, cum, probas = index.graph()
@@ -362,9 +373,9 @@ def write_index(index, fname):
             _w_vec(f, nbrs, np.int32)
             f.write(_struct.pack("<iiiii", int(p["entry_point"]), int(p["max_level"]), int(p["efConstruction"]),
                                  int(p["efSearch"]), 1))
-            _write_flat(f, index.d, index.metric_type, index.reconstruct_n(0, index.ntotal))
+            _write_flat(f, index.d, index.metric_type, rows if rows is not None else index.reconstruct_n(0, index.ntotal))
         elif isinstance(index, IndexFlat):
-            _write_flat(f, index.d, index.metric_type, index.reconstruct_n(0, index.ntotal))
+            _write_flat(f, index.d, index.metric_type, rows if rows is not None else index.reconstruct_n(0, index.ntotal))
         elif hasattr(index, "_write"):
             index._write(f)
         else:
@@ -401,7 +412,8 @@ def _read_index(f):
         idx = IndexHNSWFlat(d, M, metric)
         L = _lib.lib()
         # the neighbour table is addressed through the per-level slot counts: the file's table must
-        # be the one this build derives from M (FAISS computes it the same way, in float)
+        # be the one this build derives from M (HnswGraph::init follows FAISS's set_default_probas:
+        # float levelMult, float proba, cut at 1e-9)
         own_cum = idx.graph()[3]
         if cum.size != own_cum.size or not np.array_equal(cum, own_cum):
             raise RuntimeError("read_index: IHNf cum_nneighbor_per_level does not match M = %d" % M)

@@ -56,23 +56,30 @@ def build_index(index_mode: str, d: int):
     raise ValueError(index_mode)
 
 
-def main(argv: Optional[Sequence[str]] = None, data_dir: Optional[Path] = None, k: int = K):
-    argv = sys.argv if argv is None else argv
-    index_mode = argv[1]
-    data_dir = Path(data_dir) if data_dir is not None else _default_dir()
-    npy = data_dir / "full_sequences.npy"
-    embeddings = numpy.load(npy).astype(numpy.float32)
-    print("full_sequences", embeddings.shape)
-
+def run(embeddings: numpy.ndarray, index_mode: str, data_dir: Path, npy_size: int, k: int = K):
+    """pfam/proteins_search.py:21-57 on an array already loaded and cast: normalises ``embeddings`` IN PLACE
+    (:22 ``faiss.normalize_L2(embeddings)``), builds / writes the index, searches, saves."""
     started = time()
-    faiss.normalize_L2(embeddings)
     index = build_index(index_mode, embeddings.shape[1])
-    index.train(embeddings)
-    index.add(embeddings)
+    if index_mode == "flat":
+        # one upload: the raw rows go to the GPU, are normalised there (same kernel, same bits as
+        # faiss.normalize_L2) and come back into the caller's array -- :22's in-place contract with two
+        # PCIe crossings instead of normalise (up + down) + add (up)
+        index.train(embeddings)
+        index.add(embeddings)
+        index.normalize_rows()
+        index.reconstruct_into(embeddings)
+    else:
+        faiss.normalize_L2(embeddings)
+        index.train(embeddings)
+        index.add(embeddings)
     print(f"Index creation took {int(time() - started)}s")
     index_file = data_dir / f"full_sequences_{index_mode}.index"
-    faiss.write_index(index, str(index_file))
-    npy_size, index_size = npy.stat().st_size, index_file.stat().st_size
+    if index_mode in ("flat", "hnsw"):
+        faiss.write_index(index, str(index_file), rows=embeddings)  # (the rows are still here: no second download)
+    else:
+        faiss.write_index(index, str(index_file))
+    index_size = index_file.stat().st_size
     print(f"Embeddings: {naturalsize(npy_size)} Index: {naturalsize(index_size)} "
           f"Difference: {naturalsize(index_size - npy_size)}")
 
@@ -85,6 +92,17 @@ def main(argv: Optional[Sequence[str]] = None, data_dir: Optional[Path] = None, 
     print(f"Search took {int(time() - started)}s")
     numpy.save(data_dir / f"full_sequences_{index_mode}_scores.npy", scores)
     numpy.save(data_dir / f"full_sequences_{index_mode}_hits.npy", hits)
+    return scores, hits
+
+
+def main(argv: Optional[Sequence[str]] = None, data_dir: Optional[Path] = None, k: int = K):
+    argv = sys.argv if argv is None else argv
+    index_mode = argv[1]
+    data_dir = Path(data_dir) if data_dir is not None else _default_dir()
+    npy = data_dir / "full_sequences.npy"
+    embeddings = numpy.load(npy).astype(numpy.float32)
+    print("full_sequences", embeddings.shape)
+    run(embeddings, index_mode, data_dir, npy.stat().st_size, k)
 
 
 if __name__ == "__main__":

@@ -8,13 +8,14 @@ ctypes binding of ``oracle/libcpu_scan.so`` (``cpu_scan.c``): the OpenMP + AVX-5
 from __future__ import annotations
 
 import ctypes
+import os
 import subprocess
 from pathlib import Path
 
 import numpy as np
 
 _HERE = Path(__file__).resolve().parent
-_SO = _HERE / "libcpu_scan.so"
+_SO = Path(os.environ["CPU_SCAN_SO"]) if os.environ.get("CPU_SCAN_SO") else _HERE / "libcpu_scan.so"  # (sanitizer builds)
 _lib = None
 
 

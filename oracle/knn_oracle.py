@@ -36,7 +36,7 @@ METRIC_INNER_PRODUCT = 0
 METRIC_L2 = 1
 
 _HERE = Path(__file__).resolve().parent
-_SO = _HERE / "libknn_oracle.so"
+_SO = Path(os.environ["KNN_ORACLE_SO"]) if os.environ.get("KNN_ORACLE_SO") else _HERE / "libknn_oracle.so"  # (sanitizer builds: tools/run_asan_cpu_tests.sh)
 
 
 def build(force: bool = False) -> Path:

@@ -225,7 +225,7 @@ def test_write_read_index_roundtrip(gpu_faiss, tmp_path):
     assert np.array_equal(np.frombuffer(raw[-5 * d * 4:], np.float32).reshape(5, d), x[:5])
 
 
-def test_proteins_search_entry_point(gpu_faiss, tmp_path, capsys):
+def test_proteins_search_entry_point(gpu_faiss, oracle, tmp_path, capsys):
     """pfam/proteins_search.py:11-57 protocol on a fixture-sized 'full_sequences.npy'."""
     from knn_for_homology_amd.pfam import proteins_search
     x = np.load(GOLDEN / "pfam-20-dist" / "test.npy")
@@ -244,6 +244,50 @@ def test_proteins_search_entry_point(gpu_faiss, tmp_path, capsys):
     assert np.array_equal(flat_hits, np.load(tmp_path / "full_sequences_hnsw_hits.npy"))
     with pytest.raises(ValueError):
         proteins_search.main(["prog", "ivf"], data_dir=tmp_path)
+    # against the oracle, bit for bit: what the script saved = flat_search(normalised rows, themselves, k)
+    xo = x.astype(np.float16).astype(np.float32)
+    oracle.normalize_l2(xo)
+    Do, Io = oracle.flat_search(xo, xo, 50, 0)
+    for mode in ("flat", "hnsw"):  # (210 rows: the HNSW walk with ef >= n is exact)
+        assert np.array_equal(np.load(tmp_path / f"full_sequences_{mode}_hits.npy"), Io)
+        assert np.array_equal(np.load(tmp_path / f"full_sequences_{mode}_scores.npy").view(np.uint32), Do.view(np.uint32))
+    # the written flat index holds the normalised rows (pfam/proteins_search.py:22 normalises before :37 add)
+    back = gpu_faiss.read_index(str(tmp_path / "full_sequences_flat.index"))
+    assert np.array_equal(back.reconstruct_n(0, 210), xo)
+
+
+@pytest.mark.parametrize("mode", ["flat", "hnsw"])
+def test_proteins_search_normalises_in_place_and_uses_k_1000(gpu_faiss, oracle, tmp_path, capsys, mode):
+    """pfam/proteins_search.py:22 `faiss.normalize_L2(embeddings)` mutates the array the script holds, :49 searches with
+    k = 1000: the default k on a 1 300-row input, results against the oracle bit for bit (flat) / as exact-walk recall
+    (hnsw: ef = max(efSearch, k) = 1000 of 1 300 rows)."""
+    from knn_for_homology_amd.pfam import proteins_search
+    rng = np.random.default_rng(12)
+    n, d = 1300, 64
+    cent = rng.standard_normal((40, d)).astype(np.float32)
+    x = (cent[rng.integers(0, 40, n)] + 0.3 * rng.standard_normal((n, d))).astype(np.float32)
+    x[700] = x[3]  # a duplicate: ties go to the lower id
+    held = x.copy()
+    proteins_search.run(held, mode, tmp_path, npy_size=n * d * 4)
+    xo = x.copy()
+    oracle.normalize_l2(xo)
+    assert np.array_equal(held.view(np.uint32), xo.view(np.uint32)), "the caller's array must come back normalised, oracle bits"
+    Do, Io = oracle.flat_search(xo, xo, 1000, 0)
+    hits = np.load(tmp_path / f"full_sequences_{mode}_hits.npy")
+    scores = np.load(tmp_path / f"full_sequences_{mode}_scores.npy")
+    assert hits.shape == (n, 1000) and scores.shape == (n, 1000)
+    if mode == "flat":
+        assert np.array_equal(hits, Io) and np.array_equal(scores.view(np.uint32), Do.view(np.uint32))
+    else:
+        found = hits >= 0
+        recall = np.mean([len(np.intersect1d(a[a >= 0], b)) for a, b in zip(hits, Io)]) / 1000
+        assert recall >= 0.97, recall
+        # whatever the walk returns carries the flat search's distance bits, best first, self hit first
+        rows = np.repeat(np.arange(n), 1000).reshape(n, 1000)
+        want = oracle.pair_distances(xo, xo, rows[found], hits[found], 0)
+        assert np.array_equal(scores[found].view(np.uint32), want.view(np.uint32))
+        assert (np.diff(np.where(found, scores, -np.inf), axis=1) <= 0).all()
+        assert (hits[:, 0] == np.arange(n)).all() or (hits[700, 0] == 3 and (np.delete(hits[:, 0], 700) == np.delete(np.arange(n), 700)).all())
 
 
 @pytest.mark.parametrize("metric", [0, 1])

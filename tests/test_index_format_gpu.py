@@ -1,0 +1,256 @@
+"""Byte-level check of write_index / read_index against the FAISS 1.7.2 file layout, assembled HERE field by field
+with struct.pack -- independently of the writer in knn_for_homology_amd/faiss.py and lsh.py.  (Reference call sites:
+/root/reference/pfam/proteins_search.py:39-40 and seqvec_search/create_index.py:47 write, seqvec_search/main.py:132 and
+seqvec_search/figures/novel_benchmark.py:32 read.)
+
+FAISS 1.7.2 impl/index_write.cpp [ext: restated from the published source, FAISS itself is not installable here]:
+
+  write_index_header(idx):  int32 d | int64 ntotal | int64 dummy = 1 << 20 | int64 dummy = 1 << 20 | uint8 is_trained |
+                            int32 metric_type (0 = INNER_PRODUCT, 1 = L2) [| float metric_arg if metric_type > 1]
+  WRITEVECTOR(v):           uint64 v.size() | v.data()
+  IndexFlat:                fourcc "IxFI" (inner product) / "IxF2" (L2) | header | WRITEXBVECTOR(codes) = uint64 number
+                            of FLOATS | the floats, row-major
+  IndexHNSWFlat:            fourcc "IHNf" | header | write_HNSW | write_index(storage)  (the flat index above)
+    write_HNSW(h):          WRITEVECTOR(assign_probas: double) | WRITEVECTOR(cum_nneighbor_per_level: int32) |
+                            WRITEVECTOR(levels: int32, = top level + 1) | WRITEVECTOR(offsets: uint64, n + 1 entries) |
+                            WRITEVECTOR(neighbors: int32, -1 = empty) | int32 entry_point | int32 max_level |
+                            int32 efConstruction | int32 efSearch | int32 upper_beam
+    HNSW::set_default_probas(M, levelMult = 1 / ln M):  for level = 0, 1, ...: float proba = exp(-level / levelMult)
+                            * (1 - exp(-1 / levelMult)); stop when proba < 1e-9; cum += level == 0 ? 2 M : M
+    neighbours of node i at level l: neighbors[offsets[i] + cum[l] .. offsets[i] + cum[l + 1])
+  IndexLSH:                 fourcc "IxHe" | header | int32 nbits | uint8 rotate_data | uint8 train_thresholds |
+                            WRITEVECTOR(thresholds: float) | int32 bytes_per_vec | write_VectorTransform(rrot) |
+                            WRITEVECTOR(codes: uint8)
+    write_VectorTransform(RandomRotationMatrix):  fourcc "rrot" | uint8 have_bias | WRITEVECTOR(A: float, d_out x d_in) |
+                            WRITEVECTOR(b: float) | int32 d_in | int32 d_out | uint8 is_trained
+    code bit j of a vector lives in byte j >> 3, bit j & 7
+"""
+import math
+import struct
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def fourcc(s):
+    return s.encode("ascii")
+
+
+def header(d, ntotal, metric):
+    return struct.pack("<i", d) + struct.pack("<q", ntotal) + struct.pack("<q", 1 << 20) * 2 + struct.pack("<B", 1) + struct.pack("<i", metric)
+
+
+def vec(fmt, values):
+    values = list(values)
+    return struct.pack("<Q", len(values)) + struct.pack("<%d%s" % (len(values), fmt), *values)
+
+
+def flat_bytes(rows, metric):
+    n, d = rows.shape
+    return fourcc("IxFI" if metric == 0 else "IxF2") + header(d, n, metric) + vec("f", rows.reshape(-1).tolist())
+
+
+def default_probas(M):
+    """(assign_probas, cum_nneighbor_per_level) as HNSW::set_default_probas builds them"""
+    mult = np.float32(1.0 / math.log(M))
+    probas, cum, nn, level = [], [0], 0, 0
+    while True:
+        proba = np.float32(math.exp(float(np.float32(-level) / mult)) * (1 - math.exp(float(np.float32(-1) / mult))))
+        if proba < 1e-9:
+            break
+        probas.append(float(proba))
+        nn += 2 * M if level == 0 else M
+        cum.append(nn)
+        level += 1
+    return probas, cum
+
+
+ROWS = np.array([[0.5, -1.0, 2.0, 0.25, 3.0],
+                 [1.5, 0.0, -2.0, 4.0, -0.125],
+                 [-3.0, 7.0, 0.75, 1.0, 1.0]], np.float32)
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_index_flat_bytes(gpu_faiss, tmp_path, metric):
+    idx = gpu_faiss.IndexFlat(5, metric)
+    idx.add(ROWS)
+    f = tmp_path / "flat.index"
+    gpu_faiss.write_index(idx, str(f))
+    expect = flat_bytes(ROWS, metric)
+    assert f.read_bytes() == expect
+    # and a file assembled here loads and answers
+    g = tmp_path / "hand.index"
+    g.write_bytes(expect)
+    back = gpu_faiss.read_index(str(g))
+    assert type(back) is gpu_faiss.IndexFlat and back.d == 5 and back.ntotal == 3 and back.metric_type == metric
+    assert np.array_equal(back.reconstruct_n(0, 3), ROWS)
+    D, I = back.search(ROWS[1:2], 3)
+    assert I[0, 0] == (1 if metric == 1 else int(np.argmax(ROWS @ ROWS[1])))
+
+
+def hand_graph():
+    """6 nodes, M = 4, three levels: node 2 reaches level 2 (entry point), node 4 level 1."""
+    M = 4
+    probas, cum = default_probas(M)
+    levels = [1, 1, 3, 1, 2, 1]                       # top level + 1
+    offsets = [0]
+    for lv in levels:
+        offsets.append(offsets[-1] + cum[lv])
+    nb = [-1] * offsets[-1]
+
+    def put(node, level, ids):
+        base = offsets[node] + cum[level]
+        assert len(ids) <= cum[level + 1] - cum[level]
+        nb[base:base + len(ids)] = ids
+    put(0, 0, [1, 2, 3]); put(1, 0, [0, 2, 5]); put(2, 0, [0, 1, 3, 4, 5]); put(3, 0, [0, 2, 4]); put(4, 0, [2, 3, 5]); put(5, 0, [1, 2, 4])
+    put(2, 1, [4]); put(4, 1, [2])
+    # level 2: node 2 alone
+    return M, probas, cum, levels, offsets, nb
+
+
+def hnsw_bytes(rows, metric, M, probas, cum, levels, offsets, nb, entry, max_level, efc, efs):
+    n, d = rows.shape
+    out = fourcc("IHNf") + header(d, n, metric)
+    out += vec("d", probas) + vec("i", cum) + vec("i", levels) + vec("Q", offsets) + vec("i", nb)
+    out += struct.pack("<iiiii", entry, max_level, efc, efs, 1)
+    return out + flat_bytes(rows, metric)
+
+
+def test_default_probas_table_of_the_library(gpu_faiss):
+    """cum_nneighbor_per_level / assign_probas of the library's graph = set_default_probas restated above"""
+    for M in (4, 12, 32, 42):
+        idx = gpu_faiss.IndexHNSWFlat(8, M, 1)
+        levels, offsets, nbrs, cum, probas = idx.graph()
+        p, c = default_probas(M)
+        assert cum.tolist() == c
+        assert probas.tolist() == p, (M, probas.tolist()[:3], p[:3])
+
+
+def test_index_hnsw_flat_bytes(gpu_faiss, tmp_path):
+    rng = np.random.default_rng(3)
+    rows = rng.standard_normal((6, 4)).astype(np.float32)
+    M, probas, cum, levels, offsets, nb = hand_graph()
+    expect = hnsw_bytes(rows, 1, M, probas, cum, levels, offsets, nb, entry=2, max_level=2, efc=40, efs=16)
+    f = tmp_path / "hand_hnsw.index"
+    f.write_bytes(expect)
+    idx = gpu_faiss.read_index(str(f))
+    assert type(idx) is gpu_faiss.IndexHNSWFlat and idx.ntotal == 6 and idx.d == 4 and idx.metric_type == 1
+    lv, off, nbrs, cum2, pr = idx.graph()
+    assert (lv + 1).tolist() == levels and off.tolist() == offsets and nbrs.tolist() == nb and cum2.tolist() == cum
+    p = idx.hnsw._params()
+    assert (int(p["entry_point"]), int(p["max_level"]), int(p["efConstruction"]), int(p["efSearch"])) == (2, 2, 40, 16)
+    # written back: the very same bytes
+    g = tmp_path / "back.index"
+    gpu_faiss.write_index(idx, str(g))
+    assert g.read_bytes() == expect
+    # the graph is connected at level 0: with ef >= n the walk returns the exact neighbours
+    idx.hnsw.efSearch = 16
+    D, I = idx.search(rows, 3)
+    flat = gpu_faiss.IndexFlat(4, 1)
+    flat.add(rows)
+    Df, If = flat.search(rows, 3)
+    assert np.array_equal(I, If) and np.array_equal(D.view(np.uint32), Df.view(np.uint32))
+
+
+def test_built_hnsw_file_parses_with_the_restated_layout(gpu_faiss, tmp_path):
+    """A graph BUILT by the library (M = 42 as in pfam/proteins_search.py:30), written, then parsed here field by field."""
+    rng = np.random.default_rng(5)
+    n, d, M = 500, 16, 42
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    idx = gpu_faiss.IndexHNSWFlat(d, M, 0)
+    idx.hnsw.efSearch = 256
+    idx.add(x)
+    f = tmp_path / "built.index"
+    gpu_faiss.write_index(idx, str(f))
+    raw = f.read_bytes()
+    pos = 0
+
+    def take(fmt):
+        nonlocal pos
+        v = struct.unpack_from("<" + fmt, raw, pos)
+        pos += struct.calcsize("<" + fmt)
+        return v
+
+    def take_vec(fmt):
+        (cnt,) = take("Q")
+        return list(take("%d%s" % (cnt, fmt))) if cnt else []
+    assert raw[:4] == b"IHNf"
+    pos = 4
+    assert take("i") == (d,) and take("q") == (n,) and take("q") == (1 << 20,) and take("q") == (1 << 20,) and take("B") == (1,) and take("i") == (0,)
+    probas, cum = take_vec("d"), take_vec("i")
+    p, c = default_probas(M)
+    assert probas == p and cum == c
+    levels, offsets, nb = take_vec("i"), take_vec("Q"), take_vec("i")
+    assert len(levels) == n and min(levels) >= 1 and len(offsets) == n + 1 and offsets[0] == 0
+    assert all(offsets[i + 1] - offsets[i] == cum[levels[i]] for i in range(n)) and len(nb) == offsets[-1]
+    assert all(-1 <= v < n for v in nb)
+    entry, max_level, efc, efs, upper = take("iiiii")
+    assert levels[entry] - 1 == max_level == max(levels) - 1 and (efc, efs, upper) == (40, 256, 1)
+    assert raw[pos:] == flat_bytes(x, 0)
+
+
+def test_index_lsh_bytes(gpu_faiss, tmp_path):
+    d, nbits, n = 4, 8, 3
+    A = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1],
+                  [1, 1, 0, 0], [0, 1, -1, 0], [-1, 0, 0, 1], [0.5, -0.5, 0.5, -0.5]], np.float32)   # [d_out = nbits][d_in = d]
+    x = np.array([[1, -2, 3, -4], [-1, 2, 0.5, 0.25], [0.1, 0.1, -0.3, 0.2]], np.float32)
+    bits = (x @ A.T >= 0).astype(np.uint8)                     # bit j -> byte j >> 3, bit j & 7
+    codes = [int(sum(int(b) << j for j, b in enumerate(row))) for row in bits]
+    expect = fourcc("IxHe") + header(d, n, 1) + struct.pack("<i", nbits) + struct.pack("<BB", 1, 0) + vec("f", []) + struct.pack("<i", 1)
+    expect += fourcc("rrot") + struct.pack("<B", 0) + vec("f", A.reshape(-1).tolist()) + vec("f", []) + struct.pack("<ii", d, nbits) + struct.pack("<B", 1)
+    expect += vec("B", codes)
+    f = tmp_path / "hand_lsh.index"
+    f.write_bytes(expect)
+    idx = gpu_faiss.read_index(str(f))
+    assert type(idx).__name__ == "IndexLSH" and idx.ntotal == n and idx.nbits == nbits and idx.d == d
+    assert idx.codes().reshape(-1).tolist() == codes
+    g = tmp_path / "back_lsh.index"
+    gpu_faiss.write_index(idx, str(g))
+    assert g.read_bytes() == expect
+    # encoding the same rows with the same rotation gives the same codes
+    fresh = gpu_faiss.IndexLSH(d, nbits, _rotation=A)
+    fresh.add(x)
+    assert fresh.codes().reshape(-1).tolist() == codes
+    D, I = idx.search(x, 1)
+    assert I[:, 0].tolist() == [0, 1, 2] and (D[:, 0] == 0).all()
+
+
+def test_real_faiss_reads_our_files_and_we_read_its_files(gpu_faiss, tmp_path):
+    """Opportunistic: the day the real module is importable, both directions for IxFI / IxF2 / IHNf / IxHe."""
+    faiss = pytest.importorskip("faiss", reason="the real faiss module is not installed on this box")
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((400, 32)).astype(np.float32)
+    for metric, rmetric in ((0, faiss.METRIC_INNER_PRODUCT), (1, faiss.METRIC_L2)):
+        ours = gpu_faiss.IndexFlat(32, metric)
+        ours.add(x)
+        gpu_faiss.write_index(ours, str(tmp_path / "o.index"))
+        theirs = faiss.read_index(str(tmp_path / "o.index"))
+        assert theirs.ntotal == 400 and theirs.metric_type == rmetric
+        ref = faiss.IndexFlat(32, rmetric)
+        ref.add(x)
+        faiss.write_index(ref, str(tmp_path / "r.index"))
+        assert (tmp_path / "r.index").read_bytes() == (tmp_path / "o.index").read_bytes()
+        back = gpu_faiss.read_index(str(tmp_path / "r.index"))
+        assert np.array_equal(back.reconstruct_n(0, 400), x)
+    h = faiss.IndexHNSWFlat(32, 12, faiss.METRIC_L2)
+    h.add(x)
+    faiss.write_index(h, str(tmp_path / "h.index"))
+    back = gpu_faiss.read_index(str(tmp_path / "h.index"))
+    back.hnsw.efSearch = 64
+    h.hnsw.efSearch = 64
+    assert (back.search(x[:20], 5)[1][:, 0] == np.arange(20)).all()
+    gpu_faiss.write_index(back, str(tmp_path / "h2.index"))
+    assert (tmp_path / "h2.index").read_bytes() == (tmp_path / "h.index").read_bytes()
+    ours = gpu_faiss.IndexHNSWFlat(32, 12, 1)
+    ours.add(x)
+    gpu_faiss.write_index(ours, str(tmp_path / "oh.index"))
+    theirs = faiss.read_index(str(tmp_path / "oh.index"))
+    assert (theirs.search(x[:20], 5)[1][:, 0] == np.arange(20)).all()
+    lsh = faiss.IndexLSH(32, 64)
+    lsh.train(x)
+    lsh.add(x)
+    faiss.write_index(lsh, str(tmp_path / "l.index"))
+    back = gpu_faiss.read_index(str(tmp_path / "l.index"))
+    assert np.array_equal(back.codes(), faiss.vector_to_array(lsh.codes).reshape(400, 8))

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Host sanitizer run (-fsanitize=address,undefined for host C/C++; CPU only, no GPU needed):
+# builds libknn355_asan.so (host code instrumented, device code untouched) and the oracle / CPU-baseline libraries with
+# gcc's sanitizers, then runs the CPU test suite against them.  The log goes to profiles/rNN_asan_cpu_tests.log.
+# usage: tools/run_asan_cpu_tests.sh [round-tag]
+set -e
+TAG=${1:-r03}
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+cd "$ROOT"
+make -C knn-for-homology_amd/csrc asan
+ASAN_RT=$(/opt/rocm/lib/llvm/bin/clang --print-file-name=libclang_rt.asan-x86_64.so)
+LOG=profiles/${TAG}_asan_cpu_tests.log
+{
+  echo "# $(date -u +%Y-%m-%dT%H:%MZ) host sanitizer run: libknn355_asan.so (clang -fsanitize=address,undefined -fno-gpu-sanitize), pytest -m 'not gpu'"
+  KNN355_LIB=$ROOT/knn-for-homology_amd/libknn355_asan.so LD_PRELOAD=$ASAN_RT ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 \
+    UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 python -m pytest tests -q -m "not gpu" -p no:cacheprovider 2>&1 | tail -5
+  echo "# oracle + CPU baseline under gcc ASan/UBSan (oracle/Makefile asan): the oracle's own known-answer tests and the cpu_scan tests"
+  make -C oracle asan -s
+  GCC_ASAN=$(gcc -print-file-name=libasan.so)
+  KNN_ORACLE_SO=$ROOT/oracle/libknn_oracle_asan.so CPU_SCAN_SO=$ROOT/oracle/libcpu_scan_asan.so LD_PRELOAD=$GCC_ASAN \
+    ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
+    python -m pytest tests/test_oracle.py tests/test_cpu_scan.py tests/test_consumers.py -q -m "not gpu" -p no:cacheprovider 2>&1 | tail -5
+} | tee "$LOG"
