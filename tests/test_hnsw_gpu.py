@@ -358,3 +358,70 @@ def test_lazy_and_eager_clearing_of_the_visited_bitmaps_agree(gpu_faiss, monkeyp
     assert np.array_equal(graphs["eager"], graphs["lazy"])
     for (De, Ie), (Dl, Il) in zip(res["eager"], res["lazy"]):
         assert np.array_equal(Ie, Il) and np.array_equal(De.view(np.uint32), Dl.view(np.uint32))
+
+
+# ---- the reference's own HNSW shape: IndexHNSWFlat(d, 42, IP), efSearch = 256, all-vs-all k = 1000 -----------------
+# (/root/reference/pfam/proteins_search.py:27-31,49; FAISS walks with ef = max(efSearch, k) = 1000 there)
+@pytest.mark.parametrize("n,d", [(20000, 128), (20000, 1024)])
+def test_reference_shape_recall_against_the_sequential_oracle(gpu_faiss, ko, n, d):
+    """At a size oracle/hnsw_oracle.c builds in seconds: same M / efConstruction / ef, k = 1000 = ef.  A beam of
+    exactly k entries cannot hold the whole top k (the sequential oracle itself reaches 0.94 at d = 128 and 0.90 on
+    the Pfam-like structure -- d = 1024, 100 rows per cluster: beyond a query's own cluster the score profile is flat,
+    rank 150 scores 0.09 and rank 1000 0.06); the device path must not be worse than the oracle by more than 2 points."""
+    nq, M, k = 300, 42, 1000
+    x = _clustered(n, d, 200, 7)
+    gpu_faiss.normalize_L2(x)
+    flat = gpu_faiss.IndexFlat(d, 0)
+    flat.add(x)
+    Dt, It = flat.search(x[:nq], k)
+    ref = ko.OracleHNSW(d, M, 0, 40)
+    ref.add(x)
+    _, Ir = ref.search(x[:nq], k, 1000)
+    r_ref = _recall(Ir, It)
+    idx = gpu_faiss.IndexHNSWFlat(d, M, gpu_faiss.METRIC_INNER_PRODUCT)
+    idx.hnsw.efSearch = 256
+    idx.train(x)
+    idx.add(x)
+    D, I = idx.search(x[:nq], k)
+    r_gpu = _recall(I, It)
+    print(f"recall@1000, ef = 1000: device {r_gpu:.4f}, sequential oracle {r_ref:.4f}")
+    assert r_gpu >= r_ref - 0.02, (r_gpu, r_ref)
+    assert (I[:, 0] == np.arange(nq)).all()
+    found = I >= 0
+    rows = np.repeat(np.arange(nq), k).reshape(nq, k)
+    want = ko.oracle().pair_distances(x, x[:nq], rows[found], I[found], 0)
+    assert np.array_equal(D[found].view(np.uint32), want.view(np.uint32)), "returned distances carry the flat search's bits"
+
+
+def test_reference_shape_at_pfam_size(gpu_faiss):
+    """200 k x 1024 clustered rows through the call sequence of pfam/proteins_search.py hnsw mode (normalise in place,
+    IndexHNSWFlat(d, 42, IP), efSearch = 256, train, add, search(embeddings, 1000)): recall@1000 against the flat
+    search, self hit first, every slot filled or -1 (remove_self_hit of pfam/proteins.py:85-122 takes the result)."""
+    from knn_for_homology_amd.evaluation import remove_self_hit
+    n, d, k = 200_000, 1024, 1000
+    x = _clustered(n, d, 2000, 21)
+    gpu_faiss.normalize_L2(x)
+    idx = gpu_faiss.IndexHNSWFlat(d, 42, gpu_faiss.METRIC_INNER_PRODUCT)
+    idx.hnsw.efSearch = 256
+    idx.train(x)
+    idx.add(x)
+    D, I = idx.search(x, k)
+    assert D.shape == (n, k) and I.shape == (n, k) and I.dtype == np.int64
+    assert ((I >= -1) & (I < n)).all()
+    filled = I >= 0
+    assert filled[:, :100].all(), "a walk with ef = 1000 fills at least the first hundred slots"
+    assert (np.diff(np.where(filled, D, -np.inf), axis=1) <= 0).all(), "best first, unfilled slots last"
+    assert (I[:, 0] == np.arange(n)).mean() >= 0.999
+    flat = gpu_faiss.IndexFlat(d, 0)
+    flat.add(x)
+    sample = np.arange(0, n, 97)[:2048]
+    Dt, It = flat.search(x[sample], k)
+    r = _recall(I[sample], It)
+    r100 = _recall(I[sample][:, :100], It[:, :100])
+    print(f"recall@1000 {r:.4f}, recall@100 of the first hundred {r100:.4f}")
+    # (ef = k on 2000 clusters of 100 rows: the ranks past the query's own cluster are decided by score differences of
+    # 1e-2 among 2000 equidistant clusters; the sequential oracle loses the same ranks at the sizes it can build -- see
+    # the test above and tools/hnsw_ref_probe.py: 40 k rows of this structure, oracle 0.902, device 0.911)
+    assert r >= 0.78 and r100 >= 0.99, (r, r100)
+    hits, scores = remove_self_hit(I[:4096].copy(), D[:4096].copy())
+    assert hits.shape == (4096, k - 1)
