@@ -117,9 +117,10 @@ int knn_flat_view(knn_handle parent, knn_handle *out);
 int knn_flat_search_keys_dev(knn_handle h, const float *q_dev, int64_t nq, int64_t k,
                              uint32_t id_base, uint64_t *keys_dev, void *stream);
 /* merges nlists key lists per query ([nlists][nq][k], e.g. an all-gather
- * buffer) into final D/I on h's device, in h's metric; intermediate rounds (nlists * k >
- * 4096) use scratch memory owned by h, so merges issued through different handles (an
- * index and its view, on two streams) never share a buffer */
+ * buffer) into final D/I on h's device, in h's metric: ONE selection launch that reads the
+ * buffer in place whatever nlists * k is -- no scratch memory, nothing of h is written (h
+ * supplies the device and the metric only), so merges issued through different handles or
+ * streams cannot interfere */
 int knn_merge_keys_dev(knn_handle h, const uint64_t *keys_dev, int32_t nlists, int64_t nq, int64_t k,
                        float *D_dev, int64_t *I_dev, void *stream);
 /* pre-sizes the device storage for nrows rows (faiss has no equivalent; avoids
@@ -145,7 +146,12 @@ void knn_free(knn_handle h);
  * local scan -> ncclAllGather of the [nq][k] packed keys -> selection on one stream; the result
  * (global ids: id_base + local row) is the same on every rank and does not depend on the number
  * of shards.  librccl is dlopen'ed on first use.  (Python callers can use torch.distributed
- * instead: knn_for_homology_amd.sharded.) */
+ * instead: knn_for_homology_amd.sharded.)
+ * One search at a time per communicator: its key / gather buffers are reused, a call on another
+ * stream waits (on the GPU) for the previous call's selection.  Two searches in flight need two
+ * communicators.  A rank whose local scan fails still enters the all-gather with "no rows" so
+ * that its peers do not deadlock, and returns its error: a failure on ANY rank is a failure of
+ * the search -- exchange the return codes before trusting a result. */
 typedef struct knn_comm_s *knn_comm;
 int knn_comm_unique_id(uint8_t *id128);
 int knn_comm_create(const uint8_t *id128, int32_t world, int32_t rank, int32_t device, knn_comm *out);
@@ -155,9 +161,16 @@ int knn_sharded_search_dev(knn_handle h, knn_comm c, const float *q_dev, int64_t
 
 /* ---- faiss.IndexHNSWFlat(d, M, metric) ------------------------------------
  * pfam/proteins_search.py:27-31 (M = 42, inner product, hnsw.efSearch = 256),
- * .train (no-op) / .add :35-37, .search(x, 1000) :49.  The graph is built and walked
- * on the host; all distances come from the GPU in lock-step batches.  Results use
- * the flat index's layout; slots the walk could not fill hold id -1. */
+ * .train (no-op) / .add :35-37, .search(x, 1000) :49.  The graph lives on the host with a
+ * device mirror of its level-0 lists.  A search runs on the device: an exact scan of the
+ * rows of all nodes above level 0 picks the entry points (knn_hnsw_set_entry; 0 = FAISS's
+ * greedy descent through the upper levels, on the host), one wave per query walks level 0
+ * with a beam of ef = max(efSearch, k) entries, and the beam's rows are re-scored with the
+ * flat search's arithmetic: every returned distance carries the flat index's bits.
+ * Construction is batch-synchronous and deterministic: level-0 candidates from the same
+ * device pipeline, only the nodes above level 0 (1 in M) are linked by host walkers whose
+ * distances come from the GPU (knn_gather_distances is that offload as a public entry).
+ * Results use the flat index's layout; slots the walk could not fill hold id -1. */
 typedef struct knn_hnsw_s *knn_hnsw_handle;
 int knn_hnsw_create(int32_t d, int32_t M, int32_t metric, knn_hnsw_handle *out);
 /* index.hnsw.efSearch / index.hnsw.efConstruction (values <= 0 leave the setting alone) */

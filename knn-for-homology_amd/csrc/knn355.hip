@@ -1484,7 +1484,15 @@ __global__ __launch_bounds__(NT) void select_topk_kernel(SelectParams p)
             T = (uint32_t)(m >> 32);
             Tkey = T == 0xFFFFFFFFu ? KEY_PAD : ((uint64_t)(T + 1u) << 32);
             cnt = Tkey == KEY_PAD ? real : count_lt(Tkey);
-            if (cnt > kmax) Tkey = bracket(k, kmax, &cnt); // (heavy ties) the best k..kmax of them: no row beyond the k-th can matter
+            if (cnt > kmax) {
+                // (heavy ties into the bound) the best k..kmax of them.  For an EXACT seed k is the caller's k and no row
+                // beyond the k-th can matter.  A STATISTICAL seed searched its sample with k_sample ~ 1.25 j << the caller's
+                // k: sample rows cut here are masked out of the main scan, and one of them could belong to the caller's
+                // top k while the verification (k-th <= T) still passes.  Too many ties to hand on: the estimate is
+                // withdrawn, the caller repeats the search without it.
+                if (p.seed_stat && tid == 0 && p.fail) *p.fail = 1;
+                Tkey = bracket(k, kmax, &cnt);
+            }
         }
         cnt = min(cnt, kmax);
         const int pos = survivors_base(Tkey);
@@ -1668,17 +1676,24 @@ struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
     int device = 0;
-    int ensure(size_t need)
+    // done / s: the owner's "everything my earlier calls enqueued" event and the stream of the call in progress.  A buffer
+    // that grows goes back to the pool, which may hand it to another handle right away: whatever still uses it must have
+    // finished.  With both given that is a host wait for the OWNER's work only (its previous calls through `done`, this
+    // call's launches through `s`); rounds 1-2 called hipDeviceSynchronize() here, which also stalled the other lane and
+    // every caller stream at the first searches of a handle.  Without them (users unknown): the whole device.
+    int ensure(size_t need, hipEvent_t done = nullptr, hipStream_t s = nullptr)
     {
         int cur = 0;
         (void)hipGetDevice(&cur);
         if (need <= bytes && cur == device) return 0;
         if (p) {
-            // growing (or the device changed): kernels enqueued on any stream may still use the old
-            // buffer, and the pool would hand it to another handle right away.  Rare (first searches
-            // of a handle), so a full device wait is affordable.
             (void)hipSetDevice(device);
-            (void)hipDeviceSynchronize();
+            if (done && cur == device) {
+                (void)hipEventSynchronize(done);
+                (void)hipStreamSynchronize(s);
+            } else {
+                (void)hipDeviceSynchronize();
+            }
             (void)hipSetDevice(cur);
         }
         release();
@@ -1770,6 +1785,7 @@ struct knn_index_s {
     float *yn = nullptr; // [cap_rows + pad]
     size_t xb_bytes = 0, yn_bytes = 0; // allocation sizes (may exceed the row capacity: pooled)
     hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;               // recorded behind everything a search of this handle enqueued (DevBuf::ensure)
     hipEvent_t ev0 = nullptr, ev1 = nullptr; // the pair of the most recent scan launch
     static const int RING = 64;
     hipEvent_t ring0[RING] = {nullptr}, ring1[RING] = {nullptr};
@@ -1899,7 +1915,9 @@ extern "C" int knn_flat_create(int32_t d, int32_t metric, knn_handle *out)
     h->dp = round_up(d, 32);
     h->metric = metric;
     h->device = g_device;
-    if (const char *e = getenv("KNN355_FLAGS")) h->flags = atoi(e); // (developer A/B runs: the tuning flags every index starts with)
+#ifdef KNN355_DEV
+    if (const char *e = getenv("KNN355_FLAGS")) h->flags = atoi(e); // (developer build only, A/B runs: the tuning flags every index starts with)
+#endif
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, g_device) == hipSuccess && cus > 0) h->num_cus = cus;
@@ -1908,6 +1926,7 @@ extern "C" int knn_flat_create(int32_t d, int32_t metric, knn_handle *out)
         delete h;
         return set_err(KNN_ERR_HIP, "flat_create: stream creation failed");
     }
+    (void)hipEventCreateWithFlags(&h->done, hipEventDisableTiming); // (without it a growing buffer waits for the whole device)
     *out = h;
     return 0;
 }
@@ -1939,6 +1958,7 @@ extern "C" int knn_flat_view(knn_handle parent, knn_handle *out)
         delete h;
         return set_err(KNN_ERR_HIP, "flat_view: stream creation failed");
     }
+    (void)hipEventCreateWithFlags(&h->done, hipEventDisableTiming);
     *out = h;
     return 0;
 }
@@ -1988,6 +2008,7 @@ extern "C" void knn_free(knn_handle h)
         }
         if (h->stream) g_streams.give(h->device, h->stream); // (synchronised above)
         if (h->flag_host) (void)hipHostFree(h->flag_host);
+        if (h->done) (void)hipEventDestroy(h->done);
     }
     delete h;
 }
@@ -2470,7 +2491,7 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     const int qcap = pl.nchunks * kslot + (sstride ? k + std::max(k >> 2, 32) : 0); // (a seed sample hands on up to kmax keys)
     LevelBufs &lb = h->ws_level[level];
     const size_t nslots = (size_t)pl.nqtiles * pl.qt;
-    if (lb.qlist.ensure((size_t)nq * qcap * 8) || lb.qcnt.ensure((size_t)nq * 4) || lb.gthr.ensure(nslots * 4) || lb.qthr.ensure((size_t)nq * 4))
+    if (lb.qlist.ensure((size_t)nq * qcap * 8, h->done, s) || lb.qcnt.ensure((size_t)nq * 4, h->done, s) || lb.gthr.ensure(nslots * 4, h->done, s) || lb.qthr.ensure((size_t)nq * 4, h->done, s))
         return set_err(KNN_ERR_HIP, "search: out of device memory");
     uint64_t *qlist = (uint64_t *)lb.qlist.p;
     uint32_t *qcnt = (uint32_t *)lb.qcnt.p, *gthr = (uint32_t *)lb.gthr.p, *qthr = (uint32_t *)lb.qthr.p;
@@ -2493,22 +2514,22 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
         uint32_t *arrive = nullptr;
         const int64_t npub = (int64_t)nslots * pub_rounds * pl.nchunks;
         if (pub_rounds) {
-            if (lb.pub.ensure((size_t)npub * 8) || lb.arrive.ensure((size_t)pl.nqtiles * 4)) return set_err(KNN_ERR_HIP, "search: out of device memory");
+            if (lb.pub.ensure((size_t)npub * 8, h->done, s) || lb.arrive.ensure((size_t)pl.nqtiles * 4, h->done, s)) return set_err(KNN_ERR_HIP, "search: out of device memory");
             pub = (uint64_t *)lb.pub.p;
             arrive = (uint32_t *)lb.arrive.p;
         }
         // (the first launch of a search: it also clears the verification flag)
-        if (pl.npairs && lb.pair_ctr.ensure(((size_t)pl.npairs + 1) * 4)) return set_err(KNN_ERR_HIP, "search: out of device memory");
+        if (pl.npairs && lb.pair_ctr.ensure(((size_t)pl.npairs + 1) * 4, h->done, s)) return set_err(KNN_ERR_HIP, "search: out of device memory");
         hipLaunchKernelGGL(init_level_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, s, gthr, (int64_t)nslots, qcnt, qthr, nq,
                            reset_flag, pub, npub, arrive, (int64_t)pl.nqtiles, pl.npairs ? (uint32_t *)lb.pair_ctr.p : nullptr, (int64_t)pl.npairs);
         HIP_TRY(hipGetLastError());
     }
     if (pl.npairs && sstride) { // (the sample's own search initialised this level: the pairs' ticket counters are left)
-        if (lb.pair_ctr.ensure(((size_t)pl.npairs + 1) * 4)) return set_err(KNN_ERR_HIP, "search: out of device memory");
+        if (lb.pair_ctr.ensure(((size_t)pl.npairs + 1) * 4, h->done, s)) return set_err(KNN_ERR_HIP, "search: out of device memory");
         HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)lb.pair_ctr.p, 2, (size_t)pl.npairs, s));
         HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)((uint32_t *)lb.pair_ctr.p + pl.npairs), 0, 1, s));
     }
-    if (h->ws_lists.ensure((size_t)pl.grid * pl.qt * pl.cap * 8)) return set_err(KNN_ERR_HIP, "search: out of device memory (candidate lists)");
+    if (h->ws_lists.ensure((size_t)pl.grid * pl.qt * pl.cap * 8, h->done, s)) return set_err(KNN_ERR_HIP, "search: out of device memory (candidate lists)");
     ScanParams p = {};
     p.xb = h->xb; p.yn = h->yn; p.xq = q_dev; p.xn = xn;
     p.nb = nb; p.nq = nq; p.dp = h->dp; p.k = k; p.cap = pl.cap;
@@ -2533,7 +2554,7 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     // the pool: about a tenth of every pair's tiles (none with flags & 2)
     p.pool_tiles = pl.npairs && !(h->flags & 2) ? std::min(std::max(1, (pl.tiles_base + 5) / 10), pl.tiles_base / 4) : 0;
     if (pub_rounds) {
-        if (h->ws_defer.ensure((size_t)pl.grid * pl.qt * pl.dt * 4)) return set_err(KNN_ERR_HIP, "search: out of device memory");
+        if (h->ws_defer.ensure((size_t)pl.grid * pl.qt * pl.dt * 4, h->done, s)) return set_err(KNN_ERR_HIP, "search: out of device memory");
         p.defer = (float *)h->ws_defer.p;
     }
     const bool top = level == 0;
@@ -2583,7 +2604,9 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     sp.seed_cnt = out.seed_cnt; sp.seed_gthr = out.seed_gthr; sp.seed_qthr = out.seed_qthr; sp.seed_j = out.seed_j; sp.seed_stat = out.seed_stat;
     sp.seed_nslots = out.seed_nslots;
     sp.qthr = qthr; sp.fail = (int *)h->ws_flag.p;
-    return launch_select(sp, s, &h->ws_tmp);
+    rc = launch_select(sp, s, &h->ws_tmp);
+    if (top && h->done) (void)hipEventRecord(h->done, s); // (everything this search enqueued: see DevBuf::ensure)
+    return rc;
 }
 
 // queries [nq][dp] already on device (padded); writes sorted keys [nq][k] and/or D/I.
@@ -2594,15 +2617,15 @@ static int search_keys_impl(knn_index_s *h, const float *q_dev, int64_t nq, int 
 {
     const float *xn = nullptr;
     if (h->metric == KNN_METRIC_L2) {
-        if (h->ws_qn.ensure((size_t)nq * 4)) return set_err(KNN_ERR_HIP, "search: out of device memory");
+        if (h->ws_qn.ensure((size_t)nq * 4, h->done, s)) return set_err(KNN_ERR_HIP, "search: out of device memory");
         int rc = norms_dev_impl(q_dev, nq, h->d, h->dp, (float *)h->ws_qn.p, s);
         if (rc) return rc;
         xn = (const float *)h->ws_qn.p;
     }
-    if (h->ws_flag.ensure(64)) return set_err(KNN_ERR_HIP, "search: out of device memory");
+    if (h->ws_flag.ensure(64, h->done, s)) return set_err(KNN_ERR_HIP, "search: out of device memory");
     if (h->approx16) {
         // the scan reads bf16 queries (the fp32 ones above gave the exact norms)
-        if (h->ws_q16.ensure((size_t)nq * h->dp * 2)) return set_err(KNN_ERR_HIP, "search: out of device memory");
+        if (h->ws_q16.ensure((size_t)nq * h->dp * 2, h->done, s)) return set_err(KNN_ERR_HIP, "search: out of device memory");
         const int64_t total = nq * h->dp;
         hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)std::min<int64_t>((total / 4 + 255) / 256, 65535)), dim3(256), 0, s, q_dev, total,
                            (__bf16 *)h->ws_q16.p);
@@ -2665,7 +2688,7 @@ static int search_dev_impl(knn_index_s *h, const float *q_dev, int64_t nq, int k
     }
     const float *qp = q_dev;
     if (h->dp != h->d) {
-        if (h->ws_q.ensure((size_t)nq * h->dp * 4)) return set_err(KNN_ERR_HIP, "search: out of device memory");
+        if (h->ws_q.ensure((size_t)nq * h->dp * 4, h->done, s)) return set_err(KNN_ERR_HIP, "search: out of device memory");
         int64_t tot = nq * h->dp;
         unsigned grid = (unsigned)std::min<int64_t>((tot + 255) / 256, 65535);
         hipLaunchKernelGGL(pad_rows_kernel, dim3(grid), dim3(256), 0, s, q_dev, nq, h->d, (float *)h->ws_q.p, h->dp);
@@ -2757,17 +2780,31 @@ extern "C" int knn_merge_keys_dev(knn_handle h, const uint64_t *keys_dev, int32_
 // seed (the rows of a database tile have no candidate list of their own in that kernel, only their compact arrays)
 // and k <= 1536.  Returns 1 when it ran (D_dev / I_dev hold all n x k results, the verification flag is still to be
 // read by the caller), 0 when the plain path should be used, < 0 on error.
-static int self_search_symmetric(knn_index_s *h, int k, float *D_dev, int64_t *I_dev, hipStream_t s)
+// will self_search_symmetric take this search?  (asked BEFORE the caller sets aside device memory for the whole n x k result)
+static bool self_search_symmetric_eligible(const knn_index_s *h, int k, int *j_out = nullptr, int *qcap_out = nullptr)
 {
     const int64_t n = h->ntotal;
-    if (n < 8192 || k > KNN_WAVE_SELECT_MAX_K || k >= n || (h->flags & (8 | 16 | 512 | 1024)) || h->force_qt || h->force_chunks || h->approx16) return 0;
+    if (n < 8192 || k > KNN_WAVE_SELECT_MAX_K || k >= n || (h->flags & (8 | 16 | 512 | 1024)) || h->force_qt || h->force_chunks || h->approx16) return false;
     const int st = n >= (1 << 20) ? 64 : 32;
     const int64_t S = view_rows(n, st, 0);
     const int j = stat_seed_rank(S, n, k);
-    if (j <= 0) return 0;
+    if (j <= 0) return false;
     const double expect = 1.3 * (double)j * (double)n / (double)S + 1.25 * k;
     const int qcap = (int)std::min<double>(((int64_t)(2.0 * expect) + 1024 + 63) / 64 * 64, 1 << 20);
-    if ((double)n * qcap * 8.0 > 24.0 * (1u << 30)) return 0;
+    if ((double)n * qcap * 8.0 > 24.0 * (1u << 30)) return false;
+    if (j_out) *j_out = j;
+    if (qcap_out) *qcap_out = qcap;
+    return true;
+}
+
+static int self_search_symmetric(knn_index_s *h, int k, float *D_dev, int64_t *I_dev, hipStream_t s)
+{
+    const int64_t n = h->ntotal;
+    int j = 0, qcap = 0;
+    if (!self_search_symmetric_eligible(h, k, &j, &qcap)) return 0;
+    const int st = n >= (1 << 20) ? 64 : 32;
+    const int64_t S = view_rows(n, st, 0);
+    const double expect = 1.3 * (double)j * (double)n / (double)S + 1.25 * k;
     ScanPlan pl;
     make_plan(h, n, n, k, true, pl); // (tile shape, list capacity, LDS)
     if (pl.qt != 128 || pl.dt != 128) return 0;
@@ -3040,7 +3077,7 @@ extern "C" int knn_flat_search_self(knn_handle h, int64_t row0, int64_t nrows, i
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(h->mu);
     if (row0 < 0 || nrows < 0 || row0 + nrows > h->ntotal) return set_err(KNN_ERR_INVALID, "search_self: row range out of bounds");
-    if (row0 == 0 && nrows == h->ntotal && (size_t)nrows * k * 12 <= ((size_t)16 << 30)) {
+    if (row0 == 0 && nrows == h->ntotal && (size_t)nrows * k * 12 <= ((size_t)16 << 30) && self_search_symmetric_eligible(h, (int)k)) {
         // every row against every row: half the score tiles suffice (self_search_symmetric)
         HIP_TRY(hipSetDevice(h->device));
         if (h->ws_D.ensure((size_t)nrows * k * 4) || h->ws_I.ensure((size_t)nrows * k * 8)) return set_err(KNN_ERR_HIP, "search_self: out of device memory");
@@ -3056,10 +3093,16 @@ extern "C" int knn_flat_search_self(knn_handle h, int64_t row0, int64_t nrows, i
                 HIP_TRY(hipMemcpyAsync(D_host, h->ws_D.p, (size_t)nrows * k * 4, hipMemcpyDeviceToHost, h->stream));
                 HIP_TRY(hipMemcpyAsync(I_host, h->ws_I.p, (size_t)nrows * k * 8, hipMemcpyDeviceToHost, h->stream));
                 HIP_TRY(hipStreamSynchronize(h->stream));
+                if ((size_t)nrows * k * 12 > ((size_t)1 << 30)) { // (gigabytes of result staging are not kept with the handle)
+                    h->ws_D.release();
+                    h->ws_I.release();
+                }
                 return 0;
             }
             // a threshold estimate was too tight or a candidate array overflowed: the plain path repeats the search
         }
+        h->ws_D.release(); // (host_search works in batches: it takes what it needs)
+        h->ws_I.release();
     }
     return host_search(h, nullptr, row0, nrows, k, D_host, I_host);
 }
@@ -3331,7 +3374,8 @@ static int rccl_load()
 struct knn_comm_s {
     void *comm = nullptr;
     int world = 1, rank = 0, device = 0;
-    DevBuf keys, gathered;
+    DevBuf keys, gathered;    // this rank's keys / everybody's: one search at a time uses them (see `done`)
+    hipEvent_t done = nullptr; // recorded behind the last search's selection: a call on ANOTHER stream waits for it
     std::mutex mu;
 };
 
@@ -3372,8 +3416,10 @@ extern "C" void knn_comm_free(knn_comm_s *c)
     if (!c) return;
     if (hipSetDevice(c->device) == hipSuccess) {
         if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+        (void)hipDeviceSynchronize();
         c->keys.release();
         c->gathered.release();
+        if (c->done) (void)hipEventDestroy(c->done);
     }
     delete c;
 }
@@ -3393,16 +3439,37 @@ extern "C" int knn_sharded_search_dev(knn_handle h, knn_comm_s *c, const float *
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     const size_t nkeys = (size_t)nq * k;
-    if (c->keys.ensure(nkeys * 8) || c->gathered.ensure(nkeys * 8 * c->world)) return set_err(KNN_ERR_HIP, "sharded_search: out of device memory");
+    // The key and gather buffers belong to the communicator: a search on another stream than the previous one must not
+    // overwrite them while that one's all-gather or selection is still running -- it waits for the previous
+    // search's `done` event (on the GPU; the host does not block).  RCCL wants the collectives of one communicator
+    // issued in one order anyway.
+    if (!c->done) HIP_TRY(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
+    HIP_TRY(hipStreamWaitEvent(s, c->done, 0));
+    if (c->keys.ensure(nkeys * 8) || c->gathered.ensure(nkeys * 8 * c->world))
+        return set_err(KNN_ERR_HIP, "sharded_search: out of device memory (before the collective: the other ranks will wait for this one -- "
+                                    "treat a failure on any rank as fatal for the communicator)");
     h->last_ms = -1.f;
     rc = search_dev_impl(h, q_dev, nq, (int)k, nullptr, nullptr, (uint64_t *)c->keys.p, id_base, false, s);
-    if (rc) return rc;
+    std::string local_err;
+    if (rc) {
+        // A rank that fails locally still enters the collective -- with "no rows" for keys -- so that its peers do not
+        // hang in ncclAllGather; it returns its error afterwards.  The peers' result then lacks this shard and they
+        // cannot know: callers must treat a failure on ANY rank as a failure of the search (exchange the return codes).
+        local_err = g_err;
+        hipLaunchKernelGGL(fill_empty_kernel, dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, s, (int64_t)nkeys, h->metric,
+                           (uint64_t *)c->keys.p, (float *)nullptr, (int64_t *)nullptr);
+    }
     RCCL_TRY(g_rccl.AllGather(c->keys.p, c->gathered.p, nkeys, /* ncclUint64 */ 5, c->comm, s));
+    if (rc) {
+        (void)hipEventRecord(c->done, s);
+        return set_err(rc, local_err);
+    }
     SelectParams sp = {};
     sp.in = (const uint64_t *)c->gathered.p; sp.lm_lists = c->world; sp.lm_k = (int)k;
     sp.nq = nq; sp.k = (int)k; sp.metric = h->metric;
     sp.D = D_dev; sp.I = I_dev;
     rc = launch_select(sp, s);
+    (void)hipEventRecord(c->done, s);
     if (rc) return rc;
     if (!stream) HIP_TRY(hipStreamSynchronize(s));
     return 0;

@@ -90,7 +90,10 @@ class HipShardBackend:
     def search_keys(self, q: torch.Tensor, k: int, id_base: int, index=None) -> torch.Tensor:
         nq = q.shape[0]
         keys = torch.empty((nq, k), dtype=torch.int64, device=q.device)
-        stream = torch.cuda.current_stream(q.device).cuda_stream
+        cur = torch.cuda.current_stream(q.device)
+        stream = cur.cuda_stream
+        if stream == 0:
+            cur.synchronize()  # (see search(): the NULL stream means the library's own stream)
         _lib.check(_lib.lib().knn_flat_search_keys_dev((index or self.index)._h, q.data_ptr(), nq, k, id_base, keys.data_ptr(),
                                                        ctypes.c_void_p(stream)))
         return keys
@@ -99,7 +102,14 @@ class HipShardBackend:
         nq = q.shape[0]
         D = torch.empty((nq, k), dtype=torch.float32, device=q.device)
         I = torch.empty((nq, k), dtype=torch.int64, device=q.device)
-        stream = torch.cuda.current_stream(q.device).cuda_stream
+        cur = torch.cuda.current_stream(q.device)
+        stream = cur.cuda_stream
+        if stream == 0:
+            # torch's default stream IS the NULL stream, and the C ABI reads NULL as "use the library's own
+            # (non-blocking) stream and synchronise it": nothing orders that stream behind torch kernels still
+            # producing q (a normalisation, a gather, the copy inside .contiguous()).  Drain them first; the call
+            # below is synchronous anyway (and may then use the statistical seed and its verification).
+            cur.synchronize()
         _lib.check(_lib.lib().knn_flat_search_dev((index or self.index)._h, q.data_ptr(), nq, k, D.data_ptr(), I.data_ptr(),
                                                   ctypes.c_void_p(stream)))
         return D, I
@@ -107,7 +117,10 @@ class HipShardBackend:
     def merge(self, gathered: torch.Tensor, nlists: int, nq: int, k: int, index=None):
         D = torch.empty((nq, k), dtype=torch.float32, device=gathered.device)
         I = torch.empty((nq, k), dtype=torch.int64, device=gathered.device)
-        stream = torch.cuda.current_stream(gathered.device).cuda_stream
+        cur = torch.cuda.current_stream(gathered.device)
+        stream = cur.cuda_stream
+        if stream == 0:
+            cur.synchronize()
         # the lane's own handle: its merge scratch is private to the lane's stream
         _lib.check(_lib.lib().knn_merge_keys_dev((index or self.index)._h, gathered.data_ptr(), nlists,
                                                  nq, k, D.data_ptr(), I.data_ptr(), ctypes.c_void_p(stream)))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Why is recall@1000 ~0.81-0.84 on the Pfam-sized synthetic set at the reference's HNSW parameters (M = 42, ef = k = 1000)?
 The same data STRUCTURE (d = 1024, 100 rows per cluster, random centres) at a size the sequential CPU oracle can build:
-device walk vs oracle walk vs flat, at ef = 1000 and ef = 2000.  usage: hnsw_ref_probe.py [n] [d]"""
+device walk vs oracle walk vs flat, at ef = 1000 and ef = 2000.  usage: tests/probe_hnsw_reference_shape.py [n] [d]"""
 import sys
 import time
 from pathlib import Path

@@ -1,4 +1,5 @@
-"""GPU: IndexHNSWFlat (host graph walk, GPU distances).  FAISS's own HNSW graph is not
+"""GPU: IndexHNSWFlat (level-0 beam search and construction candidates on the device, exact coarse entry scan,
+beam rows re-scored with the flat search's arithmetic).  FAISS's own HNSW graph is not
 deterministic under OpenMP, so parity is stated the way the north star does: recall@k
 against the exact flat search, plus bit-equality of every returned distance with the flat
 kernel's distance for the same (query, row)."""
@@ -421,7 +422,7 @@ def test_reference_shape_at_pfam_size(gpu_faiss):
     print(f"recall@1000 {r:.4f}, recall@100 of the first hundred {r100:.4f}")
     # (ef = k on 2000 clusters of 100 rows: the ranks past the query's own cluster are decided by score differences of
     # 1e-2 among 2000 equidistant clusters; the sequential oracle loses the same ranks at the sizes it can build -- see
-    # the test above and tools/hnsw_ref_probe.py: 40 k rows of this structure, oracle 0.902, device 0.911)
+    # the test above and tests/probe_hnsw_reference_shape.py: 40 k rows of this structure, oracle 0.902, device 0.911)
     assert r >= 0.78 and r100 >= 0.99, (r, r100)
     hits, scores = remove_self_hit(I[:4096].copy(), D[:4096].copy())
     assert hits.shape == (4096, k - 1)

@@ -171,3 +171,33 @@ def test_query_sharded_slices_equal_the_unsharded_search(gpu_faiss, oracle):
             assert np.array_equal(D.cpu().numpy().view(np.uint32), Do[lo:hi].view(np.uint32))
             covered += hi - lo
         assert covered == n
+
+
+def test_query_sharded_search_waits_for_the_kernels_that_produce_q(gpu_faiss, oracle):
+    """on torch's default stream the C ABI gets a NULL stream (= the library's own non-blocking stream),
+    which nothing orders behind torch kernels still producing q.  The queries here are the output of a long queue of
+    torch work (the buffer holds zeros until the very last kernel): the search must see the finished queries."""
+    import torch
+    from knn_for_homology_amd.sharded import QueryShardedFlatIndex
+    rng = np.random.default_rng(77)
+    n, d, k, nq = 20000, 256, 10, 512
+    xb = rng.standard_normal((n, d), dtype=np.float32)
+    qh = rng.standard_normal((nq, d), dtype=np.float32)
+    dev = torch.device("cuda", 0)
+    x = torch.from_numpy(xb).to(dev)
+    idx = QueryShardedFlatIndex(d, 1, rank=0, world=1)
+    idx.add_dev(x)
+    Do, Io = oracle.flat_search(xb, qh, k, 1)
+    src = torch.from_numpy(qh).to(dev)
+    big = torch.randn((6144, 6144), device=dev)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        q = torch.zeros((nq, d), device=dev)
+        junk = big
+        for _ in range(12):               # ~50 ms of queued matmuls in front of the copy that fills q
+            junk = (junk @ big) * 1e-4
+        q += src + 0.0 * junk[:nq, :d].nan_to_num(0.0, 0.0, 0.0)
+        D, I = idx.search_dev(q, k)       # no synchronize in between
+        torch.cuda.synchronize()
+        assert np.array_equal(I.cpu().numpy(), Io)
+        assert np.array_equal(D.cpu().numpy().view(np.uint32), Do.view(np.uint32))

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of tuning flags (KNN355_FLAGS) on the bench's batch legs and the streaming step: tools/ab_flags.sh 0 2048 0 2048
+# A/B of tuning flags (KNN355_FLAGS) on the bench's batch legs and the streaming step: tools/ab_flags.sh 0 2048 0 2048 (needs the developer build: make -C knn-for-homology_amd/csrc trace, KNN355_LIB=.../libknn355_trace.so -- the shipped library ignores KNN355_FLAGS)
 for fl in "$@"; do
   echo "== KNN355_FLAGS=$fl"
   KNN355_FLAGS=$fl timeout -k 10 300 python bench.py --no-extras --no-cpu --steps 30 --warmup 5 2>/dev/null | python -c "
