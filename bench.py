@@ -54,8 +54,8 @@ FP32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--nb-total", type=int, default=10_000_000)
     ap.add_argument("--nq", type=int, default=32)
     ap.add_argument("--k", type=int, default=100)
@@ -500,6 +500,8 @@ def cpu_baseline(rows, q_host, k, nb_total):
         if best is None or tm < best[0]:
             best = (tm, th, n_, rec, Dc, Ic)
     t_nat, th_nat, n_nat, rec_nat, Dc, Ic = best
+    from oracle import cpu_scan as cs
+    fma_peak = cs.fma_gflops(th_nat, 0.5)  # the same threads, nothing but vector FMAs out of registers
     t1 = timed(lambda: rows.search(q_host, k, ko.METRIC_INNER_PRODUCT, threads=1), min_passes=1, budget=0.0, max_passes=1)[0] if S <= 2_500_000 else None
 
     # ---- FAISS's own algorithm on numpy's BLAS, on a sub-sample (it is 50-100x slower) ----
@@ -559,6 +561,9 @@ def cpu_baseline(rows, q_host, k, nb_total):
                       f"median of {n_used} passes of {t_used:.3f}s; value extrapolates linearly in the database size",
             "host": {"cpus_in_affinity_mask": avail, "cgroup_cpu_quota": quota, "threads_used": cores, "avx512": bool(rows_has_avx512()),
                      "dram_read_GBs": rec_nat["dram_read_GBs"], "scan_over_dram_floor": rec_nat["times_dram_floor"],
+                     "fma_peak_gflops": fma_peak, "scan_gflops": rec_nat["gflops"], "scan_over_compute_floor": fma_peak / rec_nat["gflops"],
+                     "floors": "a scan of S rows for nq queries cannot take less than S*d*4 B / dram_read_GBs nor less than 2*nq*S*d flop / "
+                               "fma_peak_gflops: with the box's CPU share the second floor is the higher one at nq = 32",
                      "single_thread_queries_per_s": (nq / (t1 * scale)) if t1 else None},
             "variants": variants, "gpu_recall_at_k_on_sample": recall}
 

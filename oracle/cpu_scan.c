@@ -120,6 +120,52 @@ double cpu_scan_read_seconds(const float *xb, int64_t n, int32_t d, int32_t thre
     return t1 - t0;
 }
 
+/* ---- the cores' own FMA rate (register-only, 16 independent accumulators per thread): the compute floor of a scan ---- */
+__attribute__((target("avx512f"))) static double fma_avx512(int64_t iters) {
+    __m512 c[16];
+    for (int i = 0; i < 16; i++) c[i] = _mm512_set1_ps(1.0f + 1e-3f * i);
+    const __m512 a = _mm512_set1_ps(1.0000001f), b = _mm512_set1_ps(1e-9f);
+    for (int64_t it = 0; it < iters; it++) {
+#pragma GCC unroll 16
+        for (int i = 0; i < 16; i++) c[i] = _mm512_fmadd_ps(c[i], a, b);
+    }
+    __m512 t = c[0];
+    for (int i = 1; i < 16; i++) t = _mm512_add_ps(t, c[i]);
+    return (double)_mm512_reduce_add_ps(t);
+}
+__attribute__((target("avx2,fma"))) static double fma_avx2(int64_t iters) {
+    __m256 c[12];
+    for (int i = 0; i < 12; i++) c[i] = _mm256_set1_ps(1.0f + 1e-3f * i);
+    const __m256 a = _mm256_set1_ps(1.0000001f), b = _mm256_set1_ps(1e-9f);
+    for (int64_t it = 0; it < iters; it++) {
+#pragma GCC unroll 12
+        for (int i = 0; i < 12; i++) c[i] = _mm256_fmadd_ps(c[i], a, b);
+    }
+    float t[8];
+    __m256 u = c[0];
+    for (int i = 1; i < 12; i++) u = _mm256_add_ps(u, c[i]);
+    _mm256_storeu_ps(t, u);
+    return (double)(t[0] + t[7]);
+}
+/* GFLOP/s of `threads` threads running nothing but vector FMAs for about `seconds` */
+double cpu_scan_fma_gflops(int32_t threads, double seconds, double *sink) {
+    if (threads <= 0) threads = omp_get_max_threads();
+    const int wide = cpu_scan_has_avx512();
+    const int64_t iters = 20 * 1000 * 1000;
+    double total = 0.0, flops = 0.0;
+    const double t0 = omp_get_wtime();
+    int rounds = 0;
+    do {
+#pragma omp parallel num_threads(threads) reduction(+ : total)
+        total += wide ? fma_avx512(iters) : fma_avx2(iters);
+        flops += (double)threads * (double)iters * (wide ? 16 * 16 * 2 : 12 * 8 * 2);
+        rounds++;
+    } while (omp_get_wtime() - t0 < seconds && rounds < 1000);
+    const double t1 = omp_get_wtime();
+    if (sink) *sink = total;
+    return flops / (t1 - t0) / 1e9;
+}
+
 /* ---- micro-kernels: 8 rows x 32 queries (AVX-512) / 4 rows x 16 queries (AVX2) ------------------
  * The queries are transposed once per search into groups qt[g][j][G] (G = 32 or 16 queries side by side), so the
  * vector dimension runs over QUERIES: for every coordinate j one broadcast of the row's y[j] feeds two FMAs, the

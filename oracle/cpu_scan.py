@@ -37,6 +37,8 @@ def lib():
         L.cpu_scan_read_seconds.restype = ctypes.c_double
         L.cpu_scan_read_seconds.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
                                             ctypes.POINTER(ctypes.c_double)]
+        L.cpu_scan_fma_gflops.restype = ctypes.c_double
+        L.cpu_scan_fma_gflops.argtypes = [ctypes.c_int32, ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
         L.cpu_scan_norms.restype = None
         L.cpu_scan_norms.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, f32p, ctypes.c_int32]
         L.cpu_scan_search.restype = ctypes.c_int
@@ -109,3 +111,9 @@ def flat_search(xb: np.ndarray, xq: np.ndarray, k: int, metric: int, threads: in
         return rows.search(xq, k, metric)
     finally:
         rows.close()
+
+
+def fma_gflops(threads: int, seconds: float = 0.5) -> float:
+    """what `threads` threads reach running nothing but vector FMAs out of registers: the compute floor of a scan"""
+    sink = ctypes.c_double()
+    return lib().cpu_scan_fma_gflops(int(threads), float(seconds), ctypes.byref(sink))
