@@ -529,11 +529,12 @@ struct ScanParams {
     int npairs;
     int pool_tiles;     // the last pool_tiles tiles of every pair's range belong to a pool shared by ALL workgroups
 #ifdef KNN355_TRACE
-    unsigned long long *trace; // developer build: [grid][64] wall-clock stamps (100 MHz) of each workgroup's progress
+    int ablate;                // developer build: 1 = skip the filter, 2 = masks only (no reservations / stores), 4 = wait for the accumulators before the stamp
+    unsigned long long *trace; // developer build: [grid][128] wall-clock stamps (100 MHz) of each workgroup's progress (64.. : inside the epilogue)
 #endif
 };
 #ifdef KNN355_TRACE
-#define KNN_TRACE(slot) do { if (threadIdx.x == 0 && p.trace && (slot) < 64) p.trace[(size_t)blockIdx.x * 64 + (slot)] = wall_clock64(); } while (0)
+#define KNN_TRACE(slot) do { if (threadIdx.x == 0 && p.trace && (slot) < 128) p.trace[(size_t)blockIdx.x * 128 + (slot)] = wall_clock64(); } while (0)
 #else
 #define KNN_TRACE(slot) do { } while (0)
 #endif
@@ -665,8 +666,10 @@ __device__ __forceinline__ void lists_compact(ListCtx &L, char *smem, int tile_r
                 L.s_cnt[ql] = keep;
                 if (n >= L.k) {
                     const uint32_t o = (uint32_t)(sb[L.k - 1] >> 32);
-                    L.s_thr[ql] = ord2f(o);
-                    atomicMin(&L.gthr[ql], o);
+                    if (o != 0xFFFFFFFFu) { // (a list may hold KEY_PAD entries -- rows that are not there: fewer than k real keys, no bound)
+                        L.s_thr[ql] = ord2f(o);
+                        atomicMin(&L.gthr[ql], o);
+                    }
                 }
             }
             __syncthreads();
@@ -863,7 +866,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
     KNN_TRACE(0);
 #ifdef KNN355_TRACE
     if (threadIdx.x == 0 && p.trace) // where this workgroup runs: HW_ID (hwreg 4) and XCC_ID (hwreg 20)
-        p.trace[(size_t)blockIdx.x * 64 + 62] = ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32) | (unsigned)__builtin_amdgcn_s_getreg(0xF804);
+        p.trace[(size_t)blockIdx.x * 128 + 62] = ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32) | (unsigned)__builtin_amdgcn_s_getreg(0xF804);
 #endif
     int64_t first_row0 = c_lo;
     while (cur_tile >= 0) {
@@ -1017,26 +1020,67 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
         };
         // threshold filter + append of one tile's scores (getv(a, b, r, xnq): from the accumulators, or read back from
         // the deferred first tile)
-        auto filter_tile = [&](int64_t trow0, auto &&getv) {
+        // Threshold filter + append of one tile's scores.  passes(a, b, r, thr, xnq): does the score beat thr; value(a, b, r,
+        // xnq): the score -- from the accumulators, or read back from the parked first tile.
+        //   This code runs beside the OTHER resident workgroup's K loop, whose MFMAs own the SIMD's issue port: per-workgroup
+        // stamps of a CATH-sized search showed the filter of round 2 (~45 vector instructions per score: row numbers, view
+        // and sample-mask arithmetic in 64 bits, the key, then a divergent append with its own LDS round trip) taking 15-60 us
+        // per tile behind a 70-110 us K loop -- about one vector instruction per MFMA of the neighbour.  So: per score ONE
+        // compare and a mask bit; everything else only for blocks of 8 scores in which some lane of the wave has a survivor,
+        // with the 8 slot reservations (one LDS atomic per score from every lane, adding 0 where the score failed: no
+        // divergence) in flight together.  Rows that are not really there (past the end in the last tile, rows of the seed
+        // sample) are found only among the survivors and stored as KEY_PAD: every reader of a list drops those.
+        auto filter_tile = [&](int64_t trow0, auto &&passes, auto &&value) {
+            const bool ragged = trow0 + DT > p.nb, sampled = p.skip_mask >= 0, plain_rows = p.row_mul == 1;
 #pragma unroll
             for (int b = 0; b < TN; b++) {
                 const int ql = (wn * TN + b) * 32 + li;
                 const int64_t q = q0 + ql;
                 const bool qok = q < p.nq;
-                const float thr = L.threshold(ql);
+                const float thr = qok ? L.threshold(ql) : -INFINITY; // (a query past the end admits nothing)
                 float xnq = 0.0f;
                 if constexpr (L2) xnq = p.xn[qok ? q : 0];
+                uint64_t *lst = L.lists + (size_t)ql * L.cap;
 #pragma unroll
                 for (int a = 0; a < TM; a++) {
                     const int64_t rbase = trow0 + (wm * TM + a) * 32 + 4 * lh;
 #pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
-                        const float v = getv(a, b, r, xnq);
-                        if (v <= thr && row < p.nb && qok && !(p.skip_mask >= 0 && ((int)(row >> p.vshift) & p.skip_mask) == 0))
-                            L.append(ql, v, p.id_base + (uint32_t)view_row(row, p.row_mul, p.vshift), DT);
+                    for (int h8 = 0; h8 < 2; h8++) {
+                        uint32_t passm = 0;
+#pragma unroll
+                        for (int r8 = 0; r8 < 8; r8++) passm |= (passes(a, b, h8 * 8 + r8, thr, xnq) ? 1u : 0u) << r8;
+                        if (__ballot(passm != 0u) == 0ull) continue;
+#ifdef KNN355_TRACE
+                        if (p.ablate & 2) continue;
+#endif
+                        int slot[8];
+#pragma unroll
+                        for (int r8 = 0; r8 < 8; r8++) slot[r8] = atomicAdd(&L.s_cnt[ql], (int)((passm >> r8) & 1u));
+                        bool near_full = false;
+#pragma unroll
+                        for (int r8 = 0; r8 < 8; r8++) {
+                            if ((passm >> r8) & 1u) {
+                                const int r = h8 * 8 + r8;
+                                const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
+                                const float vv = value(a, b, r, xnq) + 0.0f;
+                                const uint32_t id = p.id_base + (plain_rows ? (uint32_t)row : (uint32_t)view_row(row, p.row_mul, p.vshift));
+                                const bool gone = (ragged && row >= p.nb) || (sampled && ((int)(row >> p.vshift) & p.skip_mask) == 0);
+                                if (slot[r8] < L.cap) lst[slot[r8]] = gone ? KEY_PAD : (((uint64_t)f2ord(vv) << 32) | id);
+                                near_full |= slot[r8] + 1 > L.cap - DT;
+                            }
+                        }
+                        if (near_full) *L.s_need = 1;
                     }
                 }
+            }
+        };
+        // (squared L2: max(0, x) <= thr is x <= thr for every thr >= 0, and a threshold is a score or +inf)
+        auto passes_acc = [&](int a, int b, int r, float thr, float xnq) -> bool {
+            if constexpr (L2) {
+                const float ynr = s_yn[(wm * TM + a) * 32 + 4 * lh + (r & 3) + 8 * (r >> 2)];
+                return __builtin_fmaf(-2.0f, acc[a][b][r], xnq + ynr) <= thr;
+            } else {
+                return -acc[a][b][r] <= thr;
             }
         };
         constexpr int NV4 = TM * TN * 4; // 16-byte pieces of a lane's scores of one tile
@@ -1114,7 +1158,20 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
         }
 
         // ---- epilogue: threshold filter + append ----
-        if (!deferred) filter_tile(row0, score_of);
+#ifdef KNN355_TRACE
+        if (p.ablate & 4) { // all MFMA results of this wave have landed before the "K loop ended" stamp is taken
+            float sink = 0.0f;
+#pragma unroll
+            for (int a = 0; a < TM; a++)
+#pragma unroll
+                for (int b = 0; b < TN; b++) sink += acc[a][b][15];
+            if (sink == 12345.678f) KNN_TRACE(61);
+            KNN_TRACE(1 + 2 * tile_idx);
+        }
+        if (!(p.ablate & 1))
+#endif
+        if (!deferred) filter_tile(row0, passes_acc, score_of);
+        KNN_TRACE(64 + 2 * tile_idx);
         if constexpr (CAN_PUB) {
             if (pub_on && (tile_idx == 1 || (deferred && (paired ? *s_next : next_tile) < 0))) {
                 // the parked first tile (every lane reads back what it stored itself); a chunk of a single tile filters
@@ -1123,10 +1180,11 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
                 float4 pv[NV4];
 #pragma unroll
                 for (int j = 0; j < NV4; j++) pv[j] = park[(size_t)j * 256];
-                filter_tile(first_row0, [&](int a, int b, int r, float) -> float {
+                auto parked = [&](int a, int b, int r, float) -> float {
                     const float4 w = pv[(b * TM + a) * 4 + (r >> 2)];
                     return (r & 3) == 0 ? w.x : ((r & 3) == 1 ? w.y : ((r & 3) == 2 ? w.z : w.w));
-                });
+                };
+                filter_tile(first_row0, [&](int a, int b, int r, float thr, float) -> bool { return parked(a, b, r, 0.0f) <= thr; }, parked);
             }
         }
         if constexpr (SYM) {
@@ -1207,6 +1265,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
             }
         }
         __syncthreads();
+        KNN_TRACE(65 + 2 * tile_idx);
         // ---- compaction of lists that could overflow on the next tile ----
         if (paired) next_tile = *s_next;
         const bool last_tile = next_tile < 0;
@@ -1723,11 +1782,11 @@ struct DevBuf {
 #ifdef KNN355_TRACE
 static DevBuf g_trace_buf;
 static int g_trace_grid = 0;
-// developer build only: the stamps of the last top-level scan launch, [grid][64]; returns the grid
+// developer build only: the stamps of the last traced scan launch, [grid][128]; returns the grid
 extern "C" int knn_dev_trace_read(unsigned long long *out, int max_wgs)
 {
     const int n = std::min(max_wgs, g_trace_grid);
-    if (n > 0 && hipMemcpy(out, g_trace_buf.p, (size_t)n * 64 * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (n > 0 && hipMemcpy(out, g_trace_buf.p, (size_t)n * 128 * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return g_trace_grid;
 }
 #endif
@@ -1795,6 +1854,8 @@ struct knn_index_s {
     DevBuf ws_D1, ws_I1, ws_tmp3; // second set for the pipelined host search
     DevBuf ws_flag;               // [0]: a statistically seeded search failed its verification
     DevBuf ws_sym;                // work table of a symmetric all-vs-all launch
+    int sym_tiles = -1, sym_run = 0; // ... which is the table for this many tiles (run length sym_run, sym_items entries)
+    int64_t sym_items = 0;
     DevBuf ws_defer;              // tile-minimum seed: the parked first-tile scores of every workgroup
     int64_t sym_searches = 0;     // self-searches served by the symmetric path
     static const int MAX_LEVELS = 8;
@@ -2559,10 +2620,11 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     }
     const bool top = level == 0;
 #ifdef KNN355_TRACE
-    if (top) {
-        if (g_trace_buf.ensure((size_t)pl.grid * 64 * 8)) return set_err(KNN_ERR_HIP, "trace: out of device memory");
-        HIP_TRY(hipMemsetAsync(g_trace_buf.p, 0, (size_t)pl.grid * 64 * 8, s));
+    if (level == (getenv("KNN355_TRACE_LEVEL") ? atoi(getenv("KNN355_TRACE_LEVEL")) : 0)) { // (developer build: which seed level's launch is stamped)
+        if (g_trace_buf.ensure((size_t)pl.grid * 128 * 8)) return set_err(KNN_ERR_HIP, "trace: out of device memory");
+        HIP_TRY(hipMemsetAsync(g_trace_buf.p, 0, (size_t)pl.grid * 128 * 8, s));
         p.trace = (unsigned long long *)g_trace_buf.p;
+        p.ablate = getenv("KNN355_ABLATE") ? atoi(getenv("KNN355_ABLATE")) : 0;
         g_trace_grid = pl.grid;
     }
 #endif
@@ -2817,6 +2879,36 @@ static int self_search_symmetric(knn_index_s *h, int k, float *D_dev, int64_t *I
     uint64_t *qlist = (uint64_t *)lb.qlist.p;
     uint32_t *qcnt = (uint32_t *)lb.qcnt.p, *gthr = (uint32_t *)lb.gthr.p, *qthr = (uint32_t *)lb.qthr.p;
     const float *xn = h->metric == KNN_METRIC_L2 ? h->yn : nullptr; // the queries are the rows: their norms are the row norms
+    // 0. work table: workgroup = (query tile I, a run of database tiles J >= I).  The run length that minimises
+    //    rounds x (tiles + half a tile of fixed work), two workgroups per CU.  The table depends on (tiles, CUs) only: it
+    //    stays on the device between searches (uploading it between the sample pass and the main launch cost a host
+    //    round trip -- 35 us of idle GPU -- per search).
+    const int64_t slots = 2 * (int64_t)std::max(1, h->num_cus);
+    if (h->sym_tiles != T || !h->ws_sym.p) {
+        int best_tp = 16;
+        int64_t best_cost = INT64_MAX;
+        for (int tp = 6; tp <= 96; tp++) {
+            int64_t wgs = 0;
+            for (int I = 0; I < T; I++) wgs += (T - I + tp - 1) / tp;
+            const int64_t rounds = (wgs + slots - 1) / slots;
+            const int64_t cost = rounds * (2 * tp + 1);
+            if (cost < best_cost || (cost == best_cost && tp > best_tp)) { best_cost = cost; best_tp = tp; }
+        }
+        std::vector<SymItem> items;
+        for (int I = 0; I < T; I++)
+            for (int j0 = I; j0 < T; j0 += best_tp) items.push_back({I, j0, std::min(best_tp, T - j0)});
+        // long runs first: the short tails of every query tile fill the last round
+        std::stable_sort(items.begin(), items.end(), [](const SymItem &a, const SymItem &b) { return a.jcount > b.jcount; });
+        h->sym_tiles = -1;
+        if (h->ws_sym.ensure(items.size() * sizeof(SymItem), h->done, s)) return set_err(KNN_ERR_HIP, "search_self: out of device memory");
+        HIP_TRY(hipMemcpyAsync(h->ws_sym.p, items.data(), items.size() * sizeof(SymItem), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s)); // (the table is a local vector)
+        h->sym_tiles = T;
+        h->sym_run = best_tp;
+        h->sym_items = (int64_t)items.size();
+    }
+    const int best_tp = h->sym_run;
+    const size_t nitems = (size_t)h->sym_items;
     // 1. the sample pass (every row is a query, the strided sample is the database): thresholds + the sample's own candidates
     SearchOut so;
     so.keys = qlist; so.keys_stride = qcap; so.keys_fill = 0;
@@ -2824,29 +2916,9 @@ static int self_search_symmetric(knn_index_s *h, int k, float *D_dev, int64_t *I
     const int k_sample = std::min(k, j + std::max(j >> 2, 8) + 8);
     int rc = search_view(h, h->xb, xn, n, k_sample, 0, st, 0, 1, so, false, s, (int *)h->ws_flag.p);
     if (rc) return rc;
-    // 2. work table: workgroup = (query tile I, a run of database tiles J >= I).  The run length that minimises
-    //    rounds x (tiles + half a tile of fixed work), two workgroups per CU
-    const int64_t slots = 2 * (int64_t)std::max(1, h->num_cus);
-    int best_tp = 16;
-    int64_t best_cost = INT64_MAX;
-    for (int tp = 6; tp <= 96; tp++) {
-        int64_t wgs = 0;
-        for (int I = 0; I < T; I++) wgs += (T - I + tp - 1) / tp;
-        const int64_t rounds = (wgs + slots - 1) / slots;
-        const int64_t cost = rounds * (2 * tp + 1);
-        if (cost < best_cost || (cost == best_cost && tp > best_tp)) { best_cost = cost; best_tp = tp; }
-    }
-    std::vector<SymItem> items;
-    for (int I = 0; I < T; I++)
-        for (int j0 = I; j0 < T; j0 += best_tp) items.push_back({I, j0, std::min(best_tp, T - j0)});
-    // long runs first: the short tails of every query tile fill the last round
-    std::stable_sort(items.begin(), items.end(), [](const SymItem &a, const SymItem &b) { return a.jcount > b.jcount; });
-    if (h->ws_sym.ensure(items.size() * sizeof(SymItem))) return set_err(KNN_ERR_HIP, "search_self: out of device memory");
-    HIP_TRY(hipMemcpyAsync(h->ws_sym.p, items.data(), items.size() * sizeof(SymItem), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s)); // (the table is a local vector)
     const size_t per_wg = (size_t)pl.qt * pl.cap * 8;
     const int64_t max_wgs = std::max<int64_t>(slots, (int64_t)((2ull << 30) / per_wg));
-    if (h->ws_lists.ensure((size_t)std::min<int64_t>((int64_t)items.size(), max_wgs) * per_wg)) return set_err(KNN_ERR_HIP, "search_self: out of device memory (candidate lists)");
+    if (h->ws_lists.ensure((size_t)std::min<int64_t>((int64_t)nitems, max_wgs) * per_wg)) return set_err(KNN_ERR_HIP, "search_self: out of device memory (candidate lists)");
     ScanParams p = {};
     p.xb = h->xb; p.yn = h->yn; p.xq = h->xb; p.xn = xn;
     p.nb = n; p.nq = n; p.dp = h->dp; p.k = k; p.cap = pl.cap;
@@ -2870,14 +2942,14 @@ static int self_search_symmetric(knn_index_s *h, int k, float *D_dev, int64_t *I
         h->nlaunches++;
         HIP_TRY(hipEventRecord(h->ev0, s));
     }
-    for (size_t i0 = 0; i0 < items.size(); i0 += (size_t)max_wgs) {
-        const size_t cnt = std::min<size_t>((size_t)max_wgs, items.size() - i0);
+    for (size_t i0 = 0; i0 < nitems; i0 += (size_t)max_wgs) {
+        const size_t cnt = std::min<size_t>((size_t)max_wgs, nitems - i0);
         p.sym_items = (const SymItem *)h->ws_sym.p + i0;
         hipLaunchKernelGGL(kern, dim3((unsigned)cnt), dim3(256), lds, s, p);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(h->ev1, s));
-    h->last_kernel = "flat_scan_q128_d128_sym"; h->last_qt = 128; h->last_dt = 128; h->last_chunks = best_tp; h->last_grid = (int)items.size();
+    h->last_kernel = "flat_scan_q128_d128_sym"; h->last_qt = 128; h->last_dt = 128; h->last_chunks = best_tp; h->last_grid = (int)nitems;
     h->last_seed_stride = st; h->last_seed_stat = j; h->last_sample_rows = S;
     // 3. final selection of all n queries, verified against the sample's bound
     SelectParams sp = {};

@@ -35,7 +35,7 @@ for _ in range(5):
     _lib.check(L.knn_flat_search_dev(idx._h, q.data_ptr(), 32, 100, D.data_ptr(), I.data_ptr(), None))
 torch.cuda.synchronize()
 L.knn_dev_trace_read.restype = ctypes.c_int
-buf = np.zeros((2048, 64), np.uint64)
+buf = np.zeros((2048, 128), np.uint64)
 grid = L.knn_dev_trace_read(buf.ctypes.data_as(ctypes.c_void_p), 2048)
 t = buf[:grid].astype(np.float64) / 100.0  # us
 t0 = t[:, 0].min()
