@@ -81,6 +81,8 @@ int knn_flat_add(knn_handle h, const float *x_host, int64_t n);
 int knn_flat_add_dev(knn_handle h, const float *x_dev, int64_t n, void *stream);
 /* index.search(x, k) -> D float32 [nq,k], I int64 [nq,k], best first;
  * unfilled slots: I=-1, D=-FLT_MAX (IP) / +FLT_MAX (L2).
+ * Squared L2 follows FAISS's two formulas [ext: knn_L2sqr, distance_compute_blas_threshold = 20]: a call with
+ * fewer than 20 queries returns sum (x - y)^2, a larger one max(0, |x|^2 + |y|^2 - 2<x,y>).
  * cath/search.py:24, pfam/proteins_search.py:49, seqvec_search/main.py:45,
  * pfam/search.py:51, pfam/slices/slices_search.py:28 */
 int knn_flat_search(knn_handle h, const float *q_host, int64_t nq, int64_t k, float *D_host,
@@ -287,7 +289,9 @@ int32_t knn_scan_times(knn_handle h, float *out_ms, int32_t max_n);
 int knn_last_seed_info(knn_handle h, int32_t *seed_stride, int32_t *stat_rank, int64_t *stat_redo,
                        int64_t *sample_rows);
 /* force a scan configuration: query_tile in {0(auto),32,64,128}; nchunks 0=auto;
- * flags: 2 = no shared pool of tiles in a paired launch, 4 = never pair the workgroups of a one-query-tile launch (static chunks instead), 8 = no seed sample, 16 = force the exact seed, 128 = force the statistical seed
+ * flags: 32 = squared L2 by the norm formula |x|^2 + |y|^2 - 2<x,y> whatever the batch size (default: FAISS's rule --
+ * batches of fewer than 20 queries use the sum of squared differences, larger ones the norm formula),
+ * 2 = no shared pool of tiles in a paired launch, 4 = never pair the workgroups of a one-query-tile launch (static chunks instead), 8 = no seed sample, 16 = force the exact seed, 128 = force the statistical seed
  * (synchronous entry points only), 512 = never use the statistical seed, 1024 = never use the
  * symmetric launch of a whole-index self-search, 2048 = never use the tile-minimum seed (a streaming
  * search then runs its seed sample as a launch of its own), bits 12-13 = publication rounds of the

@@ -742,10 +742,19 @@ __device__ __forceinline__ void sched_spread()
 // A staged 128-byte row segment then holds 64 values instead of 32, the same 16-byte fragment feeds ONE
 // v_mfma_f32_32x32x16_bf16 instead of four fp32 MFMAs (1/16 of the matrix time), and everything else -- staging,
 // swizzle, lists, thresholds, selection -- is shared.  p.dp counts 4-byte units of a row here (d / 2).
-template <int WM, int WN, int TM, int TN, bool L2, bool NTDB = false, bool SYM = false, bool BF16 = false>
+// DIFF: FAISS's squared L2 for batches of fewer than 20 queries (distance_compute_blas_threshold [ext]; reachable through
+// seqvec_search/main.py:22-45 with metric=METRIC_L2 and a handful of queries): the sum of (x - y)^2 itself, not
+// |x|^2 + |y|^2 - 2<x,y>.  Contract: ONE fp32 chain per (query, row), acc = fma(t, t, acc) with t = x[k] - y[k], k in the
+// same order as the dot product (0,4,1,5,2,6,3,7 per block of 8).  No matrix instruction computes that: the 32-query
+// tile's staging, lists, thresholds, seeding and selection are kept and the K step's MFMAs are replaced by vector
+// subtract / fma chains -- lane (i, h) owns query i and the same 32 rows per tile whose scores the MFMA would have left
+// in its accumulator registers, so everything behind the K loop is shared.  (~2 k vector instructions per lane and K step
+// whatever the number of queries: a 10 M-row scan takes about as long as its HBM traffic.)
+template <int WM, int WN, int TM, int TN, bool L2, bool NTDB = false, bool SYM = false, bool BF16 = false, bool DIFF = false>
 __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 {
     static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(!DIFF || (L2 && !SYM && !BF16 && WN == 1 && TN == 1), "the difference build: one 32-query tile, squared L2");
     constexpr int DT = WM * TM * 32;        // database rows per tile
     constexpr int QT = WN * TN * 32;        // queries per workgroup
     constexpr int ROWS = DT + QT;           // staged rows per K step
@@ -927,6 +936,36 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
             constexpr int ND = decltype(nd_tag)::value;
             const char *A = cur;
             const char *B = cur + DT * 128;
+            if constexpr (DIFF) {
+#pragma unroll
+                for (int n = 0; n < ND; n++) dma(n); // (the next K step's staging goes out first: the chains below take microseconds)
+                const char *qrow = B + li * 128; // this lane's query (rows of B past the last query repeat it: their scores are dropped)
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const f32x4 qa = *(const f32x4 *)(qrow + (((2 * t) ^ swz) * 16));
+                    const f32x4 qb = *(const f32x4 *)(qrow + (((2 * t + 1) ^ swz) * 16));
+#pragma unroll
+                    for (int a = 0; a < TM; a++) {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const int rl = (wm * TM + a) * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
+                            const int rs = (rl >> 1) & 7;
+                            const f32x4 ya = *(const f32x4 *)(A + rl * 128 + (((2 * t) ^ rs) * 16));
+                            const f32x4 yb = *(const f32x4 *)(A + rl * 128 + (((2 * t + 1) ^ rs) * 16));
+                            float c = acc[a][0][r];
+#pragma unroll
+                            for (int m = 0; m < 4; m++) { // k = 8t + m, 8t + 4 + m: the dot product's order
+                                const float ta = qa[m] - ya[m];
+                                c = __builtin_fmaf(ta, ta, c);
+                                const float tb = qb[m] - yb[m];
+                                c = __builtin_fmaf(tb, tb, c);
+                            }
+                            acc[a][0][r] = c;
+                        }
+                    }
+                }
+                return;
+            }
             // fragments of sub-step t+1 are requested before the MFMAs of sub-step t are issued,
             // so the LDS latency hides behind the matrix pipe (two register sets, fully unrolled)
             f32x4 af[2][TM], bf[2][TN];
@@ -1010,7 +1049,9 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 
         // score of accumulator register r of MFMA tile (a, b) -- "smaller is better"
         auto score_of = [&](int a, int b, int r, float xnq) -> float {
-            if constexpr (L2) {
+            if constexpr (DIFF) {
+                return acc[a][b][r];
+            } else if constexpr (L2) {
                 const float ynr = s_yn[(wm * TM + a) * 32 + 4 * lh + (r & 3) + 8 * (r >> 2)];
                 const float v = __builtin_fmaf(-2.0f, acc[a][b][r], xnq + ynr);
                 return v < 0.0f ? 0.0f : v;
@@ -1076,7 +1117,9 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
         };
         // (squared L2: max(0, x) <= thr is x <= thr for every thr >= 0, and a threshold is a score or +inf)
         auto passes_acc = [&](int a, int b, int r, float thr, float xnq) -> bool {
-            if constexpr (L2) {
+            if constexpr (DIFF) {
+                return acc[a][b][r] <= thr;
+            } else if constexpr (L2) {
                 const float ynr = s_yn[(wm * TM + a) * 32 + 4 * lh + (r & 3) + 8 * (r >> 2)];
                 return __builtin_fmaf(-2.0f, acc[a][b][r], xnq + ynr) <= thr;
             } else {
@@ -2337,6 +2380,7 @@ static int launch_select(SelectParams sp, hipStream_t s, DevBuf *tmp = nullptr)
 struct ScanPlan {
     int qt, dt, nqtiles, nchunks, cap, grid;
     int npairs; // > 0: paired walk -- grid = nchunks = 2 npairs workgroups, tiles_base / tiles_rem split the tiles over the PAIRS
+    bool diff;  // squared L2 as the sum of squared differences (FAISS's small-batch formula), see flat_scan_kernel<..., DIFF>
     int64_t chunk_rows;
     int tiles_base, tiles_rem;
     size_t lds;
@@ -2350,6 +2394,15 @@ static int launch_scan_cfg(const knn_index_s *h, const ScanParams &p, const Scan
     const bool l2 = h->metric == KNN_METRIC_L2;
     void (*kern)(ScanParams) = nullptr;
     // one query tile: rows are read once, non-temporal staging loads
+    if constexpr (WM == 4 && TM == 2) {
+        if (plan.diff) {
+            kern = flat_scan_kernel<4, 1, 2, 1, true, true, false, false, true>;
+            HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds));
+            hipLaunchKernelGGL(kern, dim3(plan.grid), dim3(256), plan.lds, s, p);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
+    }
     if (h->approx16) {
         if (p.nqtiles == 1) kern = l2 ? flat_scan_kernel<WM, WN, TM, TN, true, true, false, true> : flat_scan_kernel<WM, WN, TM, TN, false, true, false, true>;
         else kern = l2 ? flat_scan_kernel<WM, WN, TM, TN, true, false, false, true> : flat_scan_kernel<WM, WN, TM, TN, false, false, false, true>;
@@ -2365,9 +2418,12 @@ static void make_plan(const knn_index_s *h, int64_t nb, int64_t nq, int k, bool 
 {
     int qt = h->force_qt;
     if (qt != 32 && qt != 64 && qt != 128) qt = nq <= 32 ? 32 : (nq <= 64 ? 64 : 128);
+    if (h->metric == KNN_METRIC_L2 && nq < 20 && !h->approx16 && !(h->flags & 32)) qt = 32; // (the difference build exists for the 32-query tile only)
     pl.qt = qt;
     pl.dt = qt == 32 ? 256 : 128;
-    pl.name = qt == 128 ? "flat_scan_q128_d128" : (qt == 64 ? "flat_scan_q64_d128" : "flat_scan_q32_d256");
+    // FAISS's squared L2 for fewer than 20 queries: the sum of squared differences (flags & 32: the norm formula throughout)
+    pl.diff = h->metric == KNN_METRIC_L2 && nq < 20 && qt == 32 && !h->approx16 && !(h->flags & 32);
+    pl.name = pl.diff ? "flat_scan_q32_d256_l2diff" : (qt == 128 ? "flat_scan_q128_d128" : (qt == 64 ? "flat_scan_q64_d128" : "flat_scan_q32_d256"));
     pl.nqtiles = (int)((nq + qt - 1) / qt);
     pl.cap = next_pow2_host(2 * k + pl.dt);
     if (pl.cap < 512) pl.cap = 512;

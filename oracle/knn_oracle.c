@@ -149,10 +149,21 @@ static int cmp_u64(const void *a, const void *b)
  * IndexFlat.search restated: xb [nb,d], xq [nq,d] row-major fp32.
  * D [nq,k] fp32, I [nq,k] int64, best first.  Returns 0.
  */
+/* FAISS computes squared L2 two ways [ext: IndexFlat -> knn_L2sqr, utils/distances.cpp]: batches of fewer than
+ * distance_compute_blas_threshold = 20 queries take the SIMD path, fvec_L2sqr = sum (x - y)^2; larger batches the BLAS
+ * path, |x|^2 + |y|^2 - 2<x,y> clamped at 0.  Mode 0 (default) follows that rule; 1 = the norm formula whatever the batch
+ * (the arithmetic of the large-batch kernels, used by tests that compare the two); 2 = differences whatever the batch.
+ * Contract of the difference form: one fp32 chain per pair, acc = fmaf(t, t, acc), t = x[k] - y[k], k in the dot
+ * product's order. */
+static int g_l2_mode = 0;
+void orc_set_l2_mode(int mode) { g_l2_mode = mode; }
+int orc_l2_is_direct(int64_t nq) { return g_l2_mode == 2 || (g_l2_mode == 0 && nq < 20); }
+
 int orc_flat_search(const float *xb, int64_t nb, const float *xq, int64_t nq, int d,
                     int metric, int64_t k, float *D, int64_t *I)
 {
     if (d <= 0 || k <= 0 || nb < 0 || nq < 0) return -1;
+    const int direct = metric == ORC_METRIC_L2 && orc_l2_is_direct(nq);
     const int dp = (d + 7) & ~7;
     float *yn = NULL, *xn = NULL;
     if (metric == ORC_METRIC_L2) {
@@ -192,15 +203,26 @@ int orc_flat_search(const float *xb, int64_t nb, const float *xq, int64_t nq, in
                 const float *blk = yt + (size_t)b * RB * dp;
                 float acc[RB];
                 for (int r = 0; r < RB; r++) acc[r] = 0.0f;
-                for (int s = 0; s < dp; s++) {
-                    const float qs = qp[s];
-                    const float *row = blk + (size_t)s * RB;
-                    for (int r = 0; r < RB; r++) acc[r] = fmaf(qs, row[r], acc[r]);
+                if (direct) {
+                    for (int s = 0; s < dp; s++) {
+                        const float qs = qp[s];
+                        const float *row = blk + (size_t)s * RB;
+                        for (int r = 0; r < RB; r++) {
+                            const float t = qs - row[r];
+                            acc[r] = fmaf(t, t, acc[r]);
+                        }
+                    }
+                } else {
+                    for (int s = 0; s < dp; s++) {
+                        const float qs = qp[s];
+                        const float *row = blk + (size_t)s * RB;
+                        for (int r = 0; r < RB; r++) acc[r] = fmaf(qs, row[r], acc[r]);
+                    }
                 }
                 for (int r = 0; r < RB; r++) {
                     int64_t row = b * RB + r;
                     if (row >= nb) break;
-                    float v = score_to_v(metric, acc[r], xn ? xn[qi] : 0.0f, yn ? yn[row] : 0.0f);
+                    float v = direct ? acc[r] + 0.0f : score_to_v(metric, acc[r], xn ? xn[qi] : 0.0f, yn ? yn[row] : 0.0f);
                     if (!(v < INFINITY)) continue; /* NaN / +inf ("worse than everything") never becomes a hit */
                     uint64_t key = ((uint64_t)f2ord(v) << 32) | (uint32_t)row;
                     if (hn < k) {

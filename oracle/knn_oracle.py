@@ -64,6 +64,8 @@ class Oracle:
         L.orc_flat_search.restype = ctypes.c_int
         L.orc_flat_search.argtypes = [f32p, ctypes.c_int64, f32p, ctypes.c_int64, ctypes.c_int,
                                       ctypes.c_int, ctypes.c_int64, f32p, i64p]
+        L.orc_set_l2_mode.restype = None
+        L.orc_set_l2_mode.argtypes = [ctypes.c_int]
         L.orc_pair_distances.restype = None
         L.orc_pair_distances.argtypes = [f32p, f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
                                          i64p, i64p, f32p]
@@ -83,7 +85,20 @@ class Oracle:
         self.lib.orc_norm_l2sqr(xp, x.shape[0], x.shape[1], out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
         return out
 
-    def flat_search(self, xb: np.ndarray, xq: np.ndarray, k: int, metric: int):
+    def set_l2_mode(self, mode: int) -> None:
+        """0: FAISS's rule (fewer than 20 queries -> sum of squared differences, else the norm formula); 1: the norm
+        formula whatever the batch; 2: differences whatever the batch"""
+        self.lib.orc_set_l2_mode(int(mode))
+
+    def flat_search(self, xb: np.ndarray, xq: np.ndarray, k: int, metric: int, l2_mode: int = 0):
+        """l2_mode: see set_l2_mode (applies to this call only)"""
+        self.lib.orc_set_l2_mode(int(l2_mode))
+        try:
+            return self._flat_search(xb, xq, k, metric)
+        finally:
+            self.lib.orc_set_l2_mode(0)
+
+    def _flat_search(self, xb: np.ndarray, xq: np.ndarray, k: int, metric: int):
         xb, bp = self._f32(xb)
         xq, qp = self._f32(xq)
         assert xb.ndim == 2 and xq.ndim == 2 and xb.shape[1] == xq.shape[1]

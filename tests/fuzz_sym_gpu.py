@@ -44,7 +44,7 @@ for case in range(ncases):
     idx.set_tuning(0, 0, 1024)
     Dp, Ip = idx.search_self(k)
     sample = rng.choice(n, 16, replace=False)
-    Do, Io = orc.flat_search(x, x[sample], k, metric)
+    Do, Io = orc.flat_search(x, x[sample], k, metric, l2_mode=1)  # (the search was one big batch: the norm formula)
     ok = (np.array_equal(I, Ip) and np.array_equal(D.view(np.uint32), Dp.view(np.uint32))
           and np.array_equal(I[sample], Io) and np.array_equal(D[sample].view(np.uint32), Do.view(np.uint32)))
     if not ok:

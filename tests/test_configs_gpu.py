@@ -90,7 +90,7 @@ def test_config2_flat_l2_k100_200k(gpu_faiss, oracle):
     D2, I2 = idx.search(x, k)
     _assert_same(D2, I2, D, I)
     sample = rng.choice(n, 16, replace=False)
-    Do, Io = oracle.flat_search(x, x[sample], k, 1)
+    Do, Io = oracle.flat_search(x, x[sample], k, 1, l2_mode=1)  # (the search was one big batch: FAISS's norm formula, not its small-batch one)
     _assert_same(D[sample], I[sample], Do, Io)
 
 
@@ -195,7 +195,9 @@ def test_gather_distances_matches_oracle(gpu_faiss, oracle, metric):
     qidx = np.repeat(np.arange(nq), counts).astype(np.int32)
     want = oracle.pair_distances(xb, xq, qidx, cand, metric)
     assert np.array_equal(_bits(out), _bits(want))
-    # ... which are the flat search's distances for those pairs
+    # ... which are the flat search's distances for those pairs (the norm formula: flags 32 -- a 9-query L2 search would
+    # otherwise return FAISS's small-batch sum of squared differences)
+    idx.set_tuning(0, 0, 32)
     D, I = idx.search(xq, 2048)
     for i in (2, 3, 6):
         ref = dict(zip(I[i].tolist(), _bits(D[i]).tolist()))

@@ -532,7 +532,7 @@ def test_search_self_equals_host_path(gpu_faiss, oracle, n, d, k, metric):
     D2, I2 = b.search_self(k, row0=n // 3, nrows=257)
     _assert_same(D2, I2, Dh[n // 3:n // 3 + 257], Ih[n // 3:n // 3 + 257])
     sample = rng.choice(n, 16, replace=False)
-    Do, Io = oracle.flat_search(host, host[sample], k, metric)
+    Do, Io = oracle.flat_search(host, host[sample], k, metric, l2_mode=1)  # (sampled rows of a big batch: the norm formula)
     _assert_same(Ds[sample], Is[sample], Do, Io)
     with pytest.raises(RuntimeError):
         b.search_self(k, row0=n - 5, nrows=10)
@@ -551,7 +551,7 @@ def test_cath20_sized_all_vs_all(gpu_faiss, oracle):
     srt = np.sort(hits, axis=1)
     assert (srt[:, 1:] != srt[:, :-1]).all() and hits.min() >= 0 and hits.max() < 14433
     sample = rng.choice(14433, 24, replace=False)
-    Do, Io = oracle.flat_search(x, x[sample], 301, 1)
+    Do, Io = oracle.flat_search(x, x[sample], 301, 1, l2_mode=1)  # (sampled rows of a 14433-query batch: the norm formula)
     _assert_same(scores[sample], hits[sample], Do[:, 1:], Io[:, 1:])
     # and against fp64 truth: ids only permuted inside fp32-noise clusters, distances within
     # 1e-5 of |x|^2+|y|^2 (the north star's tolerance; oracle/knn_oracle.py compare_tie_tolerant)
@@ -770,3 +770,53 @@ def test_tile_minimum_seed_with_adversarial_order(gpu_faiss, oracle):
     D, I = idx.search(xq, k)
     assert idx.last_seed()["stride"] < 0
     _assert_same(D, I, *oracle.flat_search(xb, xq, k, 0))
+
+
+# ---- FAISS's small-batch squared L2: the sum of squared differences (round 3) --------------------------------------
+@pytest.mark.parametrize("nb,d,nq,k", [(1000, 5, 1, 3), (5000, 64, 7, 10), (4097, 100, 19, 50), (300, 1024, 6, 11),
+                                       (20000, 33, 19, 100), (600_000, 32, 5, 10), (700_001, 16, 19, 100)])
+def test_l2_small_batch_is_the_sum_of_squared_differences(gpu_faiss, oracle, nb, d, nq, k):
+    """IndexFlat(d, METRIC_L2).search with fewer than 20 queries returns sum (x - y)^2 (FAISS's knn_L2sqr takes its SIMD
+    path below distance_compute_blas_threshold = 20 [ext]; reachable through seqvec_search/main.py:22-45 with
+    metric=METRIC_L2): bit for bit the oracle's difference chain, in every seeding / pairing regime; flags=32 keeps the
+    norm formula."""
+    rng = np.random.default_rng(nb + nq)
+    xb = rng.standard_normal((nb, d), dtype=np.float32)
+    xb[nb // 2: nb // 2 + 20] = xb[:20]
+    xq = np.concatenate([rng.standard_normal((nq, d), dtype=np.float32)[: max(nq - 1, 0)], xb[:1]])[:nq]
+    idx = gpu_faiss.IndexFlat(d, 1)
+    idx.add(xb)
+    D, I = idx.search(xq, k)
+    assert idx.last_scan()["kernel"] == "flat_scan_q32_d256_l2diff"
+    _assert_same(D, I, *oracle.flat_search(xb, xq, k, 1))
+    assert (D[-1, 0] == 0.0) and I[-1, 0] == 0, "a row's distance to itself is exactly 0, the lower id of a duplicate first"
+    idx.set_tuning(0, 0, 32)
+    D2, I2 = idx.search(xq, k)
+    assert idx.last_scan()["kernel"] == "flat_scan_q32_d256"
+    _assert_same(D2, I2, *oracle.flat_search(xb, xq, k, 1, l2_mode=1))
+    # both within the north star's 1e-5 (relative to the magnitudes the sums are formed from) of the fp64 truth
+    if nb <= 5000:
+        ref = np.sort(((xq[:, None, :].astype(np.float64) - xb[None].astype(np.float64)) ** 2).sum(2), 1)[:, :k]
+        scale = float((xb.astype(np.float64) ** 2).sum(1).max() + (xq.astype(np.float64) ** 2).sum(1).max())
+        assert np.abs(D - ref).max() <= 1e-5 * scale and np.abs(D2 - ref).max() <= 1e-5 * scale
+
+
+def test_l2_formula_switches_at_twenty_queries(gpu_faiss, oracle):
+    rng = np.random.default_rng(20)
+    xb = rng.standard_normal((3000, 48), dtype=np.float32)
+    xq = rng.standard_normal((20, 48), dtype=np.float32)
+    idx = gpu_faiss.IndexFlat(48, 1)
+    idx.add(xb)
+    D19, I19 = idx.search(xq[:19], 5)
+    assert idx.last_scan()["kernel"].endswith("l2diff")
+    D20, I20 = idx.search(xq, 5)
+    assert not idx.last_scan()["kernel"].endswith("l2diff")
+    _assert_same(D19, I19, *oracle.flat_search(xb, xq[:19], 5, 1))
+    _assert_same(D20, I20, *oracle.flat_search(xb, xq, 5, 1))
+    assert (D19.view(np.uint32) != D20[:19].view(np.uint32)).any(), "two formulas, two roundings"
+    # inner product has one formula
+    ip = gpu_faiss.IndexFlat(48, 0)
+    ip.add(xb)
+    Da, Ia = ip.search(xq[:19], 5)
+    Db, Ib = ip.search(xq, 5)
+    assert np.array_equal(Da.view(np.uint32), Db[:19].view(np.uint32)) and np.array_equal(Ia, Ib[:19])

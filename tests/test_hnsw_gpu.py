@@ -57,7 +57,10 @@ def test_recall_and_distance_bits(gpu_faiss, metric):
     D, I = idx.search(x[:nq], 100)
     assert _recall(I, It) >= 0.97
     # every returned (id, distance) equals the flat kernel's value for that pair, bit for bit
+    # (squared L2: the walk's rows are re-scored with the flat search's norm formula whatever the batch size -- flags 32
+    # keeps a 16-query flat search from switching to FAISS's small-batch sum of squared differences)
     full = gpu_faiss.IndexFlat(d, metric)
+    full.set_tuning(0, 0, 32)
     full.add(x)
     Dall, Iall = full.search(x[:16], 2048)
     for qi in range(16):

@@ -149,6 +149,7 @@ def test_index_hnsw_flat_bytes(gpu_faiss, tmp_path):
     idx.hnsw.efSearch = 16
     D, I = idx.search(rows, 3)
     flat = gpu_faiss.IndexFlat(4, 1)
+    flat.set_tuning(0, 0, 32)  # (the norm formula: what the walk's rows are re-scored with)
     flat.add(rows)
     Df, If = flat.search(rows, 3)
     assert np.array_equal(I, If) and np.array_equal(D.view(np.uint32), Df.view(np.uint32))
