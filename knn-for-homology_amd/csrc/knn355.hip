@@ -742,17 +742,20 @@ __device__ __forceinline__ void sched_spread()
 // A staged 128-byte row segment then holds 64 values instead of 32, the same 16-byte fragment feeds ONE
 // v_mfma_f32_32x32x16_bf16 instead of four fp32 MFMAs (1/16 of the matrix time), and everything else -- staging,
 // swizzle, lists, thresholds, selection -- is shared.  p.dp counts 4-byte units of a row here (d / 2).
-// DIFF: FAISS's squared L2 for batches of fewer than 20 queries (distance_compute_blas_threshold [ext]; reachable through
-// seqvec_search/main.py:22-45 with metric=METRIC_L2 and a handful of queries): the sum of (x - y)^2 itself, not
+// DNQ > 0 ("DIFF"): FAISS's squared L2 for batches of fewer than 20 queries (distance_compute_blas_threshold [ext]; reachable
+// through seqvec_search/main.py:22-45 with metric=METRIC_L2 and a handful of queries): the sum of (x - y)^2 itself, not
 // |x|^2 + |y|^2 - 2<x,y>.  Contract: ONE fp32 chain per (query, row), acc = fma(t, t, acc) with t = x[k] - y[k], k in the
 // same order as the dot product (0,4,1,5,2,6,3,7 per block of 8).  No matrix instruction computes that: the 32-query
 // tile's staging, lists, thresholds, seeding and selection are kept and the K step's MFMAs are replaced by vector
-// subtract / fma chains -- lane (i, h) owns query i and the same 32 rows per tile whose scores the MFMA would have left
-// in its accumulator registers, so everything behind the K loop is shared.  (~2 k vector instructions per lane and K step
-// whatever the number of queries: a 10 M-row scan takes about as long as its HBM traffic.)
-template <int WM, int WN, int TM, int TN, bool L2, bool NTDB = false, bool SYM = false, bool BF16 = false, bool DIFF = false>
+// subtract / fma chains -- thread = row of the 256-row tile (its 32 floats of the K step in registers), one chain per
+// query, the queries' floats read from LDS as broadcasts.  Behind the K loop the scores are transposed through the staging
+// buffers into the accumulator layout the MFMA would have left (lane (i, h) = query i, registers = 32 rows), so the filter,
+// the tile-minimum seed and everything else are shared.  Measured, 10 M x 1024 rows: 19.4 ms for up to 19 queries (the
+// MFMA scan with the norm formula: 7.0-7.4 ms); a build for up to 4 queries keeps a single query at its HBM time.
+template <int WM, int WN, int TM, int TN, bool L2, bool NTDB = false, bool SYM = false, bool BF16 = false, int DNQ = 0>
 __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 {
+    constexpr bool DIFF = DNQ > 0; // the difference build, for batches of up to DNQ queries (4 or 20)
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(!DIFF || (L2 && !SYM && !BF16 && WN == 1 && TN == 1), "the difference build: one 32-query tile, squared L2");
     constexpr int DT = WM * TM * 32;        // database rows per tile
@@ -906,6 +909,10 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
             for (int b = 0; b < TN; b++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
+        constexpr int DIFF_NQ = DIFF ? DNQ : 1; // (the difference build serves batches of fewer than 20 queries: one chain per query)
+        float dacc[DIFF_NQ];                   // ... as one chain per query and ROW = thread (see compute)
+#pragma unroll
+        for (int qi = 0; qi < DIFF_NQ; qi++) dacc[qi] = 0.0f;
 
         const float *tsrc[NI];
 #pragma unroll
@@ -939,30 +946,31 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
             if constexpr (DIFF) {
 #pragma unroll
                 for (int n = 0; n < ND; n++) dma(n); // (the next K step's staging goes out first: the chains below take microseconds)
-                const char *qrow = B + li * 128; // this lane's query (rows of B past the last query repeat it: their scores are dropped)
+                // thread = row tid of the tile; its 32 floats of this K step, then one chain per query (the queries' floats are
+                // broadcast reads).  k = 8t + m, 8t + 4 + m, m = 0..3: the dot product's order.
+                const int rs = (tid >> 1) & 7;
+                f32x4 y[8];
 #pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const f32x4 qa = *(const f32x4 *)(qrow + (((2 * t) ^ swz) * 16));
-                    const f32x4 qb = *(const f32x4 *)(qrow + (((2 * t + 1) ^ swz) * 16));
+                for (int sl = 0; sl < 8; sl++) y[sl] = *(const f32x4 *)(A + tid * 128 + ((sl ^ rs) * 16));
 #pragma unroll
-                    for (int a = 0; a < TM; a++) {
+                for (int qi = 0; qi < DIFF_NQ; qi++) {
+                    const char *qrow = B + qi * 128;
+                    const int qs = (qi >> 1) & 7;
+                    float c = dacc[qi];
 #pragma unroll
-                        for (int r = 0; r < 16; r++) {
-                            const int rl = (wm * TM + a) * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
-                            const int rs = (rl >> 1) & 7;
-                            const f32x4 ya = *(const f32x4 *)(A + rl * 128 + (((2 * t) ^ rs) * 16));
-                            const f32x4 yb = *(const f32x4 *)(A + rl * 128 + (((2 * t + 1) ^ rs) * 16));
-                            float c = acc[a][0][r];
+                    for (int t = 0; t < 4; t++) {
+                        const f32x4 qa = *(const f32x4 *)(qrow + (((2 * t) ^ qs) * 16));
+                        const f32x4 qb = *(const f32x4 *)(qrow + (((2 * t + 1) ^ qs) * 16));
 #pragma unroll
-                            for (int m = 0; m < 4; m++) { // k = 8t + m, 8t + 4 + m: the dot product's order
-                                const float ta = qa[m] - ya[m];
-                                c = __builtin_fmaf(ta, ta, c);
-                                const float tb = qb[m] - yb[m];
-                                c = __builtin_fmaf(tb, tb, c);
-                            }
-                            acc[a][0][r] = c;
+                        for (int m = 0; m < 4; m++) {
+                            const float ta = qa[m] - y[2 * t][m];
+                            c = __builtin_fmaf(ta, ta, c);
+                            const float tb = qb[m] - y[2 * t + 1][m];
+                            c = __builtin_fmaf(tb, tb, c);
                         }
                     }
+                    dacc[qi] = c;
+                    if ((qi & 3) == 3) __builtin_amdgcn_sched_barrier(0); // (four queries' reads in flight, not all twenty)
                 }
                 return;
             }
@@ -1044,6 +1052,22 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
         }
         __syncthreads();
         compute(((KT - 1) & 1) ? stage1 : stage0, no_dma, nd_none{});
+        if constexpr (DIFF) {
+            // the scores change hands: from "thread = row, register = query" to the accumulator layout the MFMA leaves behind
+            // (lane (i, h) = query i, registers = 32 rows), through the staging buffers -- everything behind the K loop is shared
+            static_assert(DT == 256 && QT == 32, "thread = row");
+            float *sT = (float *)smem; // [DIFF_NQ][DT]
+            __syncthreads();           // (every wave has read its last fragments)
+#pragma unroll
+            for (int qi = 0; qi < DIFF_NQ; qi++) sT[qi * DT + tid] = dacc[qi];
+            __syncthreads();
+#pragma unroll
+            for (int a = 0; a < TM; a++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    acc[a][0][r] = li < DIFF_NQ ? sT[li * DT + (wm * TM + a) * 32 + 4 * lh + (r & 3) + 8 * (r >> 2)] : INFINITY;
+            __syncthreads();           // (the next tile's prologue stages into these buffers)
+        }
         KNN_TRACE(1 + 2 * tile_idx);
         if (paired && tid == 0) *s_next = next_tile; // (read by everyone behind the barrier that ends the epilogue)
 
@@ -2396,7 +2420,8 @@ static int launch_scan_cfg(const knn_index_s *h, const ScanParams &p, const Scan
     // one query tile: rows are read once, non-temporal staging loads
     if constexpr (WM == 4 && TM == 2) {
         if (plan.diff) {
-            kern = flat_scan_kernel<4, 1, 2, 1, true, true, false, false, true>;
+            // (a build for up to 4 queries -- a single query scans at the speed of its HBM traffic -- and one for up to 19)
+            kern = p.nq <= 4 ? flat_scan_kernel<4, 1, 2, 1, true, true, false, false, 4> : flat_scan_kernel<4, 1, 2, 1, true, true, false, false, 20>;
             HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds));
             hipLaunchKernelGGL(kern, dim3(plan.grid), dim3(256), plan.lds, s, p);
             HIP_TRY(hipGetLastError());
