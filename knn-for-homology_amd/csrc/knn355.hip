@@ -1364,6 +1364,11 @@ struct SelectParams {
     const uint32_t *cnt;
     int n_fixed, cap;
     int n_expect;         // host's estimate of a typical count (0: cap) -- picks the build, any count is handled
+    // end-of-search reset (streaming searches with the tile-minimum seed): the final selection leaves the level's state the
+    // way init_level_kernel would -- the next search of the same shape needs no launch in front of its scan
+    uint32_t *rs_gthr, *rs_qcnt, *rs_qthr, *rs_arrive, *rs_pair;
+    uint64_t *rs_pub;
+    int rs_nslots, rs_pub_n, rs_narrive, rs_npairs;
     int seg_len, nseg;    // segment pass (nseg > 0): workgroup (q, s) selects among keys [s * seg_len, (s + 1) * seg_len) of query q
                           // and writes output row q * nseg + s
     int lm_lists, lm_k;
@@ -1666,6 +1671,19 @@ __global__ __launch_bounds__(NT) void select_topk_kernel(SelectParams p)
             const uint32_t kth = cnt >= k ? (uint32_t)(sb[k - 1] >> 32) : 0xFFFFFFFFu;
             if (kth > p.qthr[q]) *p.fail = 1;
         }
+        if (p.rs_gthr) { // (this query's candidates have been read: barriers above)
+            if (tid == 0) {
+                p.rs_qcnt[q] = 0u;
+                p.rs_qthr[q] = 0xFFFFFFFFu;
+                p.rs_gthr[q] = 0xFFFFFFFFu;
+            }
+            for (int j = tid; j < p.rs_pub_n; j += NT) p.rs_pub[(size_t)q * p.rs_pub_n + j] = KEY_PAD;
+            if (q == 0) {
+                for (int64_t i = p.nq + tid; i < p.rs_nslots; i += NT) p.rs_gthr[i] = 0xFFFFFFFFu;
+                for (int i = tid; i < p.rs_narrive; i += NT) p.rs_arrive[i] = 0u;
+                for (int i = tid; i <= p.rs_npairs; i += NT) p.rs_pair[i] = i < p.rs_npairs ? 2u : 0u;
+            }
+        }
     }
 }
 
@@ -1864,6 +1882,7 @@ struct LevelBufs {
     DevBuf qlist, qcnt, gthr, qthr;
     DevBuf pub, arrive; // tile-minimum seed: published keys [nslots][rounds * nchunks], arrival counters [nqtiles]
     DevBuf pair_ctr;    // paired walk: ticket counter of every pair of workgroups
+    uint64_t clean_sig = 0; // != 0: the last search's selection reset this state for a search of exactly this shape
 };
 
 // HIP streams are recycled: creating one costs a third of a millisecond, and the reference's scripts build a fresh
@@ -2000,6 +2019,7 @@ extern "C" int knn_normalize_l2_dev(float *x_dev, int64_t n, int32_t d, void *st
     return 0;
 }
 
+static void *pool_alloc(size_t bytes, int device, size_t *got);
 extern "C" int knn_normalize_l2(float *x_host, int64_t n, int32_t d)
 {
     if (n < 0 || d <= 0) return set_err(KNN_ERR_INVALID, "normalize_l2: bad shape");
@@ -2007,25 +2027,56 @@ extern "C" int knn_normalize_l2(float *x_host, int64_t n, int32_t d)
     if (!x_host) return set_err(KNN_ERR_INVALID, "normalize_l2: null pointer");
     int rc = ensure_device(g_device);
     if (rc) return rc;
-    // stream through a bounded device buffer (<= 1 GiB)
-    const int64_t rows_per = std::max<int64_t>(1, (int64_t)(1ull << 30) / ((int64_t)d * 4));
-    const int64_t nb = std::min(n, rows_per);
-    float *buf = nullptr;
-    HIP_TRY(hipMalloc((void **)&buf, (size_t)nb * d * 4));
-    for (int64_t i0 = 0; i0 < n; i0 += nb) {
-        int64_t m = std::min(nb, n - i0);
-        hipError_t e = hipMemcpy(buf, x_host + i0 * d, (size_t)m * d * 4, hipMemcpyHostToDevice);
+    // Two pooled device buffers (no hipMalloc / hipFree per call: the reference's scripts normalise per embedding file)
+    // and two streams taking turns in chunks of <= 64 MB: the download of chunk i overlaps the upload of chunk i + 1 (PCIe
+    // is full duplex).  (A caller that adds the rows to an index anyway should add them raw and use knn_flat_normalize_rows
+    // + knn_flat_reconstruct: one crossing each way -- pfam/proteins_search.py's flat mode does.)
+    const int64_t rows_per = std::max<int64_t>(1, (int64_t)(64ull << 20) / ((int64_t)d * 4));
+    const int64_t nbuf = std::min(n, rows_per);
+    float *buf[2] = {nullptr, nullptr};
+    size_t got[2] = {0, 0};
+    hipStream_t st[2] = {nullptr, nullptr};
+    auto cleanup = [&]() {
+        for (int i = 0; i < 2; i++) {
+            if (st[i]) {
+                (void)hipStreamSynchronize(st[i]);
+                g_streams.give(g_device, st[i]);
+            }
+            if (buf[i]) g_pool.give(buf[i], got[i], g_device);
+        }
+    };
+    const int lanes = n > nbuf ? 2 : 1;
+    for (int i = 0; i < lanes; i++) {
+        buf[i] = (float *)pool_alloc((size_t)nbuf * d * 4, g_device, &got[i]);
+        st[i] = g_streams.take(g_device);
+        if (!buf[i] || !st[i]) {
+            cleanup();
+            return set_err(KNN_ERR_HIP, "normalize_l2: out of device memory");
+        }
+    }
+    int turn = 0;
+    for (int64_t i0 = 0; i0 < n; i0 += nbuf, turn ^= (lanes - 1)) {
+        const int64_t m = std::min(nbuf, n - i0);
+        hipError_t e = hipStreamSynchronize(st[turn]); // (this buffer's previous chunk is home)
+        if (e == hipSuccess) e = hipMemcpyAsync(buf[turn], x_host + i0 * d, (size_t)m * d * 4, hipMemcpyHostToDevice, st[turn]);
         if (e == hipSuccess) {
-            rc = normalize_dev_impl(buf, m, d, d, nullptr);
-            if (rc) { (void)hipFree(buf); return rc; }
-            e = hipMemcpy(x_host + i0 * d, buf, (size_t)m * d * 4, hipMemcpyDeviceToHost);
+            rc = normalize_dev_impl(buf[turn], m, d, d, st[turn]);
+            if (rc) { cleanup(); return rc; }
+            e = hipMemcpyAsync(x_host + i0 * d, buf[turn], (size_t)m * d * 4, hipMemcpyDeviceToHost, st[turn]);
         }
         if (e != hipSuccess) {
-            (void)hipFree(buf);
+            cleanup();
             return set_err(KNN_ERR_HIP, std::string("normalize_l2 copy: ") + hipGetErrorString(e));
         }
     }
-    HIP_TRY(hipFree(buf));
+    for (int i = 0; i < lanes; i++) {
+        hipError_t e = hipStreamSynchronize(st[i]);
+        if (e != hipSuccess) {
+            cleanup();
+            return set_err(KNN_ERR_HIP, std::string("normalize_l2: ") + hipGetErrorString(e));
+        }
+    }
+    cleanup();
     return 0;
 }
 
@@ -2632,6 +2683,7 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     if (pl.chunk_rows == pl.dt && pl.dt > kslot && pl.dt <= pl.cap - pl.dt && k <= KNN_WAVE_SELECT_MAX_K) kslot = pl.dt;
     const int qcap = pl.nchunks * kslot + (sstride ? k + std::max(k >> 2, 32) : 0); // (a seed sample hands on up to kmax keys)
     LevelBufs &lb = h->ws_level[level];
+    uint64_t reset_sig = 0; // != 0: this search's final selection resets the level's state for a successor of the same shape
     const size_t nslots = (size_t)pl.nqtiles * pl.qt;
     if (lb.qlist.ensure((size_t)nq * qcap * 8, h->done, s) || lb.qcnt.ensure((size_t)nq * 4, h->done, s) || lb.gthr.ensure(nslots * 4, h->done, s) || lb.qthr.ensure((size_t)nq * 4, h->done, s))
         return set_err(KNN_ERR_HIP, "search: out of device memory");
@@ -2639,6 +2691,7 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     uint32_t *qcnt = (uint32_t *)lb.qcnt.p, *gthr = (uint32_t *)lb.gthr.p, *qthr = (uint32_t *)lb.qthr.p;
     int rc;
     if (sstride) {
+        lb.clean_sig = 0;
         // the sample's sorted top-k opens every query's candidate array; its seed_j-th score is the
         // running threshold the main pass starts from
         SearchOut so;
@@ -2662,9 +2715,22 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
         }
         // (the first launch of a search: it also clears the verification flag)
         if (pl.npairs && lb.pair_ctr.ensure(((size_t)pl.npairs + 1) * 4, h->done, s)) return set_err(KNN_ERR_HIP, "search: out of device memory");
-        hipLaunchKernelGGL(init_level_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, s, gthr, (int64_t)nslots, qcnt, qthr, nq,
-                           reset_flag, pub, npub, arrive, (int64_t)pl.nqtiles, pl.npairs ? (uint32_t *)lb.pair_ctr.p : nullptr, (int64_t)pl.npairs);
-        HIP_TRY(hipGetLastError());
+        // A streaming search whose predecessor on this handle had exactly this shape finds the state already reset: that
+        // search's final selection did it (SelectParams::rs_*) -- one launch and a ~10 us launch gap less per step.
+        if (pub_rounds && pl.npairs && !(h->flags & 64)) {
+            uint64_t sig = 0x9E3779B97F4A7C15ull;
+            const uint64_t parts[] = {(uint64_t)nslots, (uint64_t)nq, (uint64_t)npub, (uint64_t)pl.nqtiles, (uint64_t)pl.npairs, (uint64_t)(uintptr_t)gthr,
+                                      (uint64_t)(uintptr_t)qcnt, (uint64_t)(uintptr_t)qthr, (uint64_t)(uintptr_t)pub, (uint64_t)(uintptr_t)arrive,
+                                      (uint64_t)(uintptr_t)lb.pair_ctr.p, (uint64_t)(uintptr_t)h->ws_flag.p};
+            for (uint64_t v : parts) sig = (sig ^ v) * 0x100000001B3ull;
+            reset_sig = sig ? sig : 1;
+        }
+        if (!(reset_sig && lb.clean_sig == reset_sig)) {
+            hipLaunchKernelGGL(init_level_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, s, gthr, (int64_t)nslots, qcnt, qthr, nq,
+                               reset_flag, pub, npub, arrive, (int64_t)pl.nqtiles, pl.npairs ? (uint32_t *)lb.pair_ctr.p : nullptr, (int64_t)pl.npairs);
+            HIP_TRY(hipGetLastError());
+        }
+        lb.clean_sig = 0; // (until this search's own selection has been enqueued)
     }
     if (pl.npairs && sstride) { // (the sample's own search initialised this level: the pairs' ticket counters are left)
         if (lb.pair_ctr.ensure(((size_t)pl.npairs + 1) * 4, h->done, s)) return set_err(KNN_ERR_HIP, "search: out of device memory");
@@ -2747,7 +2813,14 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     sp.seed_cnt = out.seed_cnt; sp.seed_gthr = out.seed_gthr; sp.seed_qthr = out.seed_qthr; sp.seed_j = out.seed_j; sp.seed_stat = out.seed_stat;
     sp.seed_nslots = out.seed_nslots;
     sp.qthr = qthr; sp.fail = (int *)h->ws_flag.p;
+    if (reset_sig && out.seed_cnt == nullptr) {
+        sp.rs_gthr = gthr; sp.rs_qcnt = qcnt; sp.rs_qthr = qthr; sp.rs_nslots = (int)nslots;
+        sp.rs_pub = (uint64_t *)lb.pub.p; sp.rs_pub_n = pub_rounds * pl.nchunks;
+        sp.rs_arrive = (uint32_t *)lb.arrive.p; sp.rs_narrive = pl.nqtiles;
+        sp.rs_pair = (uint32_t *)lb.pair_ctr.p; sp.rs_npairs = pl.npairs;
+    }
     rc = launch_select(sp, s, &h->ws_tmp);
+    if (!rc && sp.rs_gthr) lb.clean_sig = reset_sig;
     if (top && h->done) (void)hipEventRecord(h->done, s); // (everything this search enqueued: see DevBuf::ensure)
     return rc;
 }
@@ -2954,6 +3027,7 @@ static int self_search_symmetric(knn_index_s *h, int k, float *D_dev, int64_t *I
     const int T = (int)((n + 127) / 128);
     const size_t nslots = (size_t)T * 128;
     LevelBufs &lb = h->ws_level[0];
+    lb.clean_sig = 0; // (this search leaves the level's state in its own shape)
     if (lb.qlist.ensure((size_t)n * qcap * 8) || lb.qcnt.ensure((size_t)n * 4) || lb.gthr.ensure(nslots * 4) || lb.qthr.ensure((size_t)n * 4) ||
         h->ws_flag.ensure(64))
         return set_err(KNN_ERR_HIP, "search_self: out of device memory");

@@ -820,3 +820,30 @@ def test_l2_formula_switches_at_twenty_queries(gpu_faiss, oracle):
     Da, Ia = ip.search(xq[:19], 5)
     Db, Ib = ip.search(xq, 5)
     assert np.array_equal(Da.view(np.uint32), Db[:19].view(np.uint32)) and np.array_equal(Ia, Ib[:19])
+
+
+def test_streaming_searches_back_to_back_reuse_the_reset_state(gpu_faiss, oracle):
+    """A streaming search whose predecessor had the same shape skips its state-reset launch (the predecessor's final
+    selection left the thresholds, counts, publications and ticket counters reset).  Sequences of searches with changing
+    queries, batch sizes, k and metrics -- and the same sequence with the reset launch forced (flags 64) -- all return the
+    oracle's bits."""
+    rng = np.random.default_rng(64)
+    nb, d = 620_000, 32
+    xb = rng.standard_normal((nb, d), dtype=np.float32)
+    xb[1000:1100] = xb[:100]
+    qs = [rng.standard_normal((nq, d), dtype=np.float32) for nq in (32, 32, 32, 7, 7, 32, 1, 1, 64, 64, 32)]
+    ks = [100, 100, 10, 10, 10, 100, 5, 5, 20, 20, 100]
+    for metric in (0, 1):
+        for flags in (0, 64):
+            idx = gpu_faiss.IndexFlat(d, metric)
+            idx.add(xb)
+            idx.set_tuning(0, 0, flags)
+            for q, k in zip(qs, ks):
+                D, I = idx.search(q, k)
+                _assert_same(D, I, *oracle.flat_search(xb, q, k, metric))
+            # the index's own rows as queries, twice in a row (squared L2: a row finds its lower-id duplicate first)
+            for _ in range(2):
+                D, I = idx.search(xb[1000:1032], 3)
+                _assert_same(D, I, *oracle.flat_search(xb, xb[1000:1032], 3, metric))
+                if metric == 1:
+                    assert (I[:, 0] == np.arange(32)).all() and (D[:, 0] == 0).all()
