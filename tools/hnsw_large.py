@@ -71,4 +71,11 @@ for efs in (128, 256, 512, 1024):
     print(f"  efSearch={efs}: {nq / t:.0f} q/s, recall@100 {rec:.4f}", flush=True)
 out = {"max_batch": max_batch, "efConstruction": efc, "rows": n, "d": d, "M": M, "k": k, "nq": nq, "centres": ncent, "build_s": t_build, "build_rows_per_s": n / t_build,
        "flat_queries_per_s": nq / t_flat, "hnsw": res, "stats": idx.stats()}
+if hasattr(L, "knn_dev_hnsw_profile"):
+    import ctypes
+    prof = (ctypes.c_double * 8)()
+    L.knn_dev_hnsw_profile(prof, 0)
+    names = ["host walkers (upper levels)", "level-0 candidates (device)", "forward selection", "forward links + sort of reverse requests",
+             "reverse links appended", "reverse pruning", "mirror + coarse update", "mirror rebuild in front of a batch"]
+    out["build_profile_s"] = {n: round(prof[i], 3) for i, n in enumerate(names) if n != "-"}
 print(json.dumps(out))
