@@ -694,14 +694,35 @@ __device__ __forceinline__ void lists_flush(ListCtx &L, int *s_base, int64_t q0,
         s_base[ql] = n > 0 ? (int)atomicAdd(&qcnt[q0 + ql], (uint32_t)n) : 0;
     }
     __syncthreads();
-    for (int ql = wave; ql < nqv; ql += NT / 64) {
-        const int n = L.s_cnt[ql], base = s_base[ql];
-        const uint64_t *lst = L.lists + (size_t)ql * L.cap;
-        uint64_t *dst = qlist + (size_t)(q0 + ql) * qcap + base;
-        for (int i = lane; i < n; i += 64)
-            if (base + i < qcap) dst[i] = lst[i];
-        // (only a symmetric launch sizes the arrays by expectation: an overflow there repeats the search the plain way)
-        if (fail && lane == 0 && base + n > qcap) *fail = 1;
+    // four queries per step and wave: their loads go out together (one query at a time, a 128-query workgroup spent 57 us
+    // here waiting for 64 dependent round trips to L2 -- 3 % of a CATH-sized symmetric launch with its short runs)
+    constexpr int NW = NT / 64, U = 4;
+    for (int ql0 = wave; ql0 < nqv; ql0 += NW * U) {
+        uint64_t v[U][2];
+        int n[U], base[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int ql = ql0 + u * NW;
+            n[u] = ql < nqv ? L.s_cnt[ql] : 0;
+            base[u] = ql < nqv ? s_base[ql] : 0;
+            const uint64_t *lst = L.lists + (size_t)(ql < nqv ? ql : 0) * L.cap;
+#pragma unroll
+            for (int j = 0; j < 2; j++) v[u][j] = lane + 64 * j < n[u] ? ((gptr_u64)lst)[lane + 64 * j] : KEY_PAD;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int ql = ql0 + u * NW;
+            if (ql >= nqv) continue;
+            const uint64_t *lst = L.lists + (size_t)ql * L.cap;
+            uint64_t *dst = qlist + (size_t)(q0 + ql) * qcap + base[u];
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+                if (lane + 64 * j < n[u] && base[u] + lane + 64 * j < qcap) dst[lane + 64 * j] = v[u][j];
+            for (int i = lane + 128; i < n[u]; i += 64)
+                if (base[u] + i < qcap) dst[i] = lst[i];
+            // (only a symmetric launch sizes the arrays by expectation: an overflow there repeats the search the plain way)
+            if (fail && lane == 0 && base[u] + n[u] > qcap) *fail = 1;
+        }
     }
 }
 
@@ -1255,7 +1276,11 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
             }
         }
         if constexpr (SYM) {
+#ifdef KNN355_TRACE
+            if (off_diag && !(p.ablate & 8)) {
+#else
             if (off_diag) {
+#endif
                 // the same scores, read the other way round: row R of this tile is a query, the resident tile's rows
                 // are its candidates.  A (register, lane half) pair of one wave is one row R and 32 candidates.
                 auto score = [&](int a, int b, int r, float xnq) -> float {
@@ -3097,6 +3122,13 @@ static int self_search_symmetric(knn_index_s *h, int k, float *D_dev, int64_t *I
         h->nlaunches++;
         HIP_TRY(hipEventRecord(h->ev0, s));
     }
+#ifdef KNN355_TRACE
+    if (g_trace_buf.ensure((size_t)nitems * 128 * 8)) return set_err(KNN_ERR_HIP, "trace: out of device memory");
+    HIP_TRY(hipMemsetAsync(g_trace_buf.p, 0, (size_t)nitems * 128 * 8, s));
+    p.trace = (unsigned long long *)g_trace_buf.p;
+    p.ablate = getenv("KNN355_ABLATE") ? atoi(getenv("KNN355_ABLATE")) : 0;
+    g_trace_grid = (int)std::min<size_t>(nitems, (size_t)max_wgs);
+#endif
     for (size_t i0 = 0; i0 < nitems; i0 += (size_t)max_wgs) {
         const size_t cnt = std::min<size_t>((size_t)max_wgs, nitems - i0);
         p.sym_items = (const SymItem *)h->ws_sym.p + i0;

@@ -847,3 +847,18 @@ def test_streaming_searches_back_to_back_reuse_the_reset_state(gpu_faiss, oracle
                 _assert_same(D, I, *oracle.flat_search(xb, xb[1000:1032], 3, metric))
                 if metric == 1:
                     assert (I[:, 0] == np.arange(32)).all() and (D[:, 0] == 0).all()
+
+
+def test_normalize_l2_in_chunks_matches_oracle(gpu_faiss, oracle):
+    """faiss.normalize_L2 on a host array larger than one staging chunk (64 MB): two pooled device buffers and two streams
+    take turns; every row carries the oracle's bits, zero rows stay untouched, the array is normalised in place."""
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((70_001, 512), dtype=np.float32) * rng.uniform(0.01, 30.0, (70_001, 1)).astype(np.float32)
+    x[123] = 0.0
+    x[-1] = 0.0
+    want = x.copy()
+    oracle.normalize_l2(want)
+    held = x
+    gpu_faiss.normalize_L2(held)
+    assert held is x and np.array_equal(x.view(np.uint32), want.view(np.uint32))
+    assert not x[123].any() and not x[-1].any()

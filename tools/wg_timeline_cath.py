@@ -15,15 +15,19 @@ x = torch.randn((n, d), generator=g, device=dev)
 idx = faiss.IndexFlat(d, 1)
 _lib.check(L.knn_flat_add_dev(idx._h, x.data_ptr(), n, None))
 D = torch.empty((n, k), device=dev, dtype=torch.float32); I = torch.empty((n, k), device=dev, dtype=torch.int64)
+SELF = len(sys.argv) > 1 and sys.argv[1] == "self"  # the symmetric whole-index self-search instead of the plain search
 for _ in range(4):
-    _lib.check(L.knn_flat_search_dev(idx._h, x.data_ptr(), n, k, D.data_ptr(), I.data_ptr(), None))
+    if SELF:
+        _lib.check(L.knn_flat_search_self_dev(idx._h, k, D.data_ptr(), I.data_ptr()))
+    else:
+        _lib.check(L.knn_flat_search_dev(idx._h, x.data_ptr(), n, k, D.data_ptr(), I.data_ptr(), None))
 torch.cuda.synchronize()
 L.knn_dev_trace_read.restype = ctypes.c_int
 buf = np.zeros((4096, 128), np.uint64)
 grid = L.knn_dev_trace_read(buf.ctypes.data_as(ctypes.c_void_p), 4096)
 t = buf[:grid].astype(np.float64) / 100.0
 t0 = t[:, 0][t[:, 0] > 0].min()
-print(f"level {os.environ.get('KNN355_TRACE_LEVEL', '0')} grid {grid}")
+print(f"level {os.environ.get('KNN355_TRACE_LEVEL', '0')} grid {grid} {'self-search' if SELF else 'plain'} last scan {idx.last_scan()}")
 start, end = t[:, 0] - t0, t[:, 63] - t0
 print(f"start: min {start.min():.1f} med {np.median(start):.1f} p90 {np.percentile(start,90):.1f} max {start.max():.1f};  end: min {end.min():.1f} med {np.median(end):.1f} max {end.max():.1f} us")
 ntiles = int(((t[:, 1:63:2] > 0).sum(1)).max())
