@@ -493,12 +493,14 @@ def cpu_baseline(rows, q_host, k, nb_total):
     for th in cand:
         tm, n_, lo, hi, (Dc, Ic) = timed(lambda: rows.search(q_host, k, ko.METRIC_INNER_PRODUCT, threads=th), min_passes=3, budget=4.0, max_passes=20)
         rd = min(rows.read_seconds(th) for _ in range(3))
-        rec = {"threads": th, "median_s_on_sample": tm, "passes": n_, "min_s": lo, "max_s": hi, "queries_per_s": nq / (tm * scale),
-               "scan_GBs": S * d * 4 / tm / 1e9, "gflops": 2.0 * nq * S * d / tm / 1e9, "dram_read_GBs": S * d * 4 / rd / 1e9,
-               "times_dram_floor": tm / rd}
+        # (the host is shared with other jobs: the BEST pass is what this CPU path can do, and the baseline gets the benefit of
+        # the doubt; the median is reported beside it)
+        rec = {"threads": th, "best_s_on_sample": lo, "median_s_on_sample": tm, "passes": n_, "max_s": hi, "queries_per_s": nq / (lo * scale),
+               "queries_per_s_median": nq / (tm * scale), "scan_GBs": S * d * 4 / lo / 1e9, "gflops": 2.0 * nq * S * d / lo / 1e9,
+               "dram_read_GBs": S * d * 4 / rd / 1e9, "times_dram_floor": lo / rd}
         variants[f"native_avx512_openmp_t{th}"] = rec
-        if best is None or tm < best[0]:
-            best = (tm, th, n_, rec, Dc, Ic)
+        if best is None or lo < best[0]:
+            best = (lo, th, n_, rec, Dc, Ic)
     t_nat, th_nat, n_nat, rec_nat, Dc, Ic = best
     from oracle import cpu_scan as cs
     fma_peak = cs.fma_gflops(th_nat, 0.5)  # the same threads, nothing but vector FMAs out of registers
@@ -558,7 +560,7 @@ def cpu_baseline(rows, q_host, k, nb_total):
     recall = ko.recall_at_k(Ig, Im)
     return {"value": value, "unit": "queries/s", "cores": cores, "kind": kind, "variant": what,
             "sample": f"first {S} of {nb_total} database rows ({S * d * 4 / 1e9:.1f} GB in host memory), {nq} queries, k={k}; "
-                      f"median of {n_used} passes of {t_used:.3f}s; value extrapolates linearly in the database size",
+                      f"best of {n_used} passes ({t_used:.3f}s; the host is shared); value extrapolates linearly in the database size",
             "host": {"cpus_in_affinity_mask": avail, "cgroup_cpu_quota": quota, "threads_used": cores, "avx512": bool(rows_has_avx512()),
                      "dram_read_GBs": rec_nat["dram_read_GBs"], "scan_over_dram_floor": rec_nat["times_dram_floor"],
                      "fma_peak_gflops": fma_peak, "scan_gflops": rec_nat["gflops"], "scan_over_compute_floor": fma_peak / rec_nat["gflops"],

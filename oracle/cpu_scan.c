@@ -214,6 +214,24 @@ __attribute__((target("avx2,fma"))) static void scores_avx2(const float *const y
     }
 }
 
+/* which of a row's G scores pass their query's threshold (v <= thr): one or two vector compares instead of G scalar ones --
+ * after the first few thousand rows almost nothing passes */
+__attribute__((target("avx512f"))) static uint32_t pass_mask_avx512(const float *sc, const float *thr, const float *xn, float ynr, int metric) {
+    uint32_t m = 0;
+    for (int h = 0; h < 2; h++) {
+        const __m512 s = _mm512_loadu_ps(sc + 16 * h), t = _mm512_loadu_ps(thr + 16 * h);
+        __m512 v;
+        if (metric == 0) {
+            v = _mm512_sub_ps(_mm512_setzero_ps(), s);
+        } else {
+            v = _mm512_sub_ps(_mm512_add_ps(_mm512_loadu_ps(xn + 16 * h), _mm512_set1_ps(ynr)), _mm512_add_ps(s, s));
+            v = _mm512_max_ps(v, _mm512_setzero_ps());
+        }
+        m |= (uint32_t)_mm512_cmp_ps_mask(v, t, _CMP_LE_OQ) << (16 * h);
+    }
+    return m;
+}
+
 static float dot_scalar(const float *a, const float *b, int32_t d) {
     float t = 0.f;
     for (int32_t j = 0; j < d; j++) t += a[j] * b[j];
@@ -309,7 +327,9 @@ int cpu_scan_search(const float *xb, const float *yn, int64_t nb, const float *x
                     const float *tg = thr + g * G;
                     for (int rr = 0; rr < rows; rr++) {
                         const float ynr = metric == 1 ? yn[r + rr] : 0.f;
-                        for (int qq = 0; qq < G; qq++) {
+                        uint32_t pm = wide ? pass_mask_avx512(sc + rr * G, tg, xn + g * G, ynr, metric) : 0xFFFFu;
+                        for (int qq = 0; qq < G && pm; qq++, pm >>= 1) {
+                            if (!(pm & 1u)) continue;
                             float v;
                             if (metric == 0) {
                                 v = -sc[rr * G + qq];
