@@ -2786,6 +2786,10 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     p.npairs = pl.npairs;
     // the pool: about a tenth of every pair's tiles (none with flags & 2)
     p.pool_tiles = pl.npairs && !(h->flags & 2) ? std::min(std::max(1, (pl.tiles_base + 5) / 10), pl.tiles_base / 4) : 0;
+#ifdef KNN355_DEV
+    if (p.pool_tiles && getenv("KNN355_POOL_PCT")) // (developer build: the pool's share of every pair's range, in percent)
+        p.pool_tiles = std::min(std::max(1, pl.tiles_base * atoi(getenv("KNN355_POOL_PCT")) / 100), pl.tiles_base - 2);
+#endif
     if (pub_rounds) {
         if (h->ws_defer.ensure((size_t)pl.grid * pl.qt * pl.dt * 4, h->done, s)) return set_err(KNN_ERR_HIP, "search: out of device memory");
         p.defer = (float *)h->ws_defer.p;

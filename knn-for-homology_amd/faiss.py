@@ -330,12 +330,24 @@ def _w_vec(f, arr, dtype):
     f.write(a.tobytes())
 
 
-def _r_vec(f, dtype):
-    (n,) = _struct.unpack("<Q", f.read(8))
-    a = np.frombuffer(f.read(n * np.dtype(dtype).itemsize), dtype=dtype)
-    if a.size != n:
+def _r_exact(f, nbytes):
+    b = f.read(nbytes)
+    if len(b) != nbytes:
         raise RuntimeError("read_index: truncated file")
-    return a
+    return b
+
+
+def _r_vec(f, dtype):
+    (n,) = _struct.unpack("<Q", _r_exact(f, 8))
+    item = np.dtype(dtype).itemsize
+    # (a corrupted count must not turn into a multi-terabyte read request: the payload cannot be longer than the file)
+    here = f.tell()
+    f.seek(0, 2)
+    left = f.tell() - here
+    f.seek(here)
+    if n * item > left:
+        raise RuntimeError("read_index: truncated or corrupted file (vector of %d items, %d bytes left)" % (n, left))
+    return np.frombuffer(_r_exact(f, n * item), dtype=dtype)
 
 
 def _w_header(f, fourcc, d, ntotal, metric):
@@ -344,9 +356,11 @@ def _w_header(f, fourcc, d, ntotal, metric):
 
 
 def _r_header(f):
-    d, ntotal, _, _, trained, metric = _struct.unpack("<iqqq?i", f.read(4 + 8 * 3 + 1 + 4))
+    d, ntotal, _, _, trained, metric = _struct.unpack("<iqqq?i", _r_exact(f, 4 + 8 * 3 + 1 + 4))
     if metric > 1:
-        f.read(4)  # metric_arg
+        _r_exact(f, 4)  # metric_arg
+    if d <= 0 or d > (1 << 20) or ntotal < 0 or metric not in (METRIC_INNER_PRODUCT, METRIC_L2):
+        raise RuntimeError("read_index: corrupted header (d=%d, ntotal=%d, metric=%d)" % (d, ntotal, metric))
     return d, ntotal, metric
 
 
@@ -406,9 +420,17 @@ def _read_index(f):
         levels = _r_vec(f, np.int32)
         offsets = _r_vec(f, np.uint64)
         nbrs = _r_vec(f, np.int32)
-        entry, max_level, efc, efs, _upper = _struct.unpack("<iiiii", f.read(20))
+        entry, max_level, efc, efs, _upper = _struct.unpack("<iiiii", _r_exact(f, 20))
+        if levels.size != ntotal or offsets.size != ntotal + 1 or cum.size < 2 or (ntotal and int(offsets[-1]) != nbrs.size):
+            raise RuntimeError("read_index: IHNf tables do not fit ntotal = %d" % ntotal)
+        if ntotal and (levels.min() < 1 or levels.max() >= cum.size):
+            raise RuntimeError("read_index: IHNf level table out of range")
         storage = _read_index(f)
+        if not isinstance(storage, IndexFlat) or storage.ntotal != ntotal or storage.d != d:
+            raise RuntimeError("read_index: IHNf storage does not match the graph")
         M = int(cum[2] - cum[1]) if cum.size > 2 else int(cum[1] // 2)
+        if M < 2 or M > 512 or int(cum[1]) != 2 * M:
+            raise RuntimeError("read_index: IHNf neighbour table does not describe an HNSW graph (M = %d)" % M)
         idx = IndexHNSWFlat(d, M, metric)
         L = _lib.lib()
         # the neighbour table is addressed through the per-level slot counts: the file's table must

@@ -91,16 +91,19 @@ class IndexLSH(Index):
     @classmethod
     def _read(cls, f):
         d, ntotal, _metric = _r_header(f)
-        nbits, rotate, thr = struct.unpack("<i??", f.read(6))
+        from .faiss import _r_exact
+        nbits, rotate, thr = struct.unpack("<i??", _r_exact(f, 6))
         _r_vec(f, np.float32)
-        (code_size,) = struct.unpack("<i", f.read(4))
+        (code_size,) = struct.unpack("<i", _r_exact(f, 4))
         if f.read(4) != b"rrot":
             raise RuntimeError("read_index: IndexLSH without a random rotation block")
-        f.read(1)
+        _r_exact(f, 1)
         A = _r_vec(f, np.float32)
         _r_vec(f, np.float32)
-        d_in, d_out, _tr = struct.unpack("<ii?", f.read(9))
+        d_in, d_out, _tr = struct.unpack("<ii?", _r_exact(f, 9))
         codes = _r_vec(f, np.uint8)
+        if nbits <= 0 or code_size != (nbits + 7) // 8 or codes.size != ntotal * code_size or (A.size and (d_in != d or d_out < nbits or A.size != d_in * d_out)):
+            raise RuntimeError("read_index: IxHe tables do not fit the header")
         idx = cls(d, nbits, rotate_data=rotate, _rotation=A.reshape(d_out, d_in)[:nbits] if A.size else None)
         if ntotal:
             c = np.ascontiguousarray(codes.reshape(ntotal, code_size))

@@ -255,3 +255,49 @@ def test_real_faiss_reads_our_files_and_we_read_its_files(gpu_faiss, tmp_path):
     faiss.write_index(lsh, str(tmp_path / "l.index"))
     back = gpu_faiss.read_index(str(tmp_path / "l.index"))
     assert np.array_equal(back.codes(), faiss.vector_to_array(lsh.codes).reshape(400, 8))
+
+
+def test_truncated_and_corrupted_files_are_refused_not_crashed_on(gpu_faiss, tmp_path):
+    """read_index on damaged IHNf / IxF2 / IxHe files: every truncation is refused with an exception; random byte damage is
+    either refused or yields an index that answers a search -- never a crash, a hang or an absurd allocation."""
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((300, 16)).astype(np.float32)
+    files = {}
+    h = gpu_faiss.IndexHNSWFlat(16, 6, 1)
+    h.add(x)
+    gpu_faiss.write_index(h, str(tmp_path / "h.index"))
+    files["h"] = (tmp_path / "h.index").read_bytes()
+    fl = gpu_faiss.IndexFlat(16, 1)
+    fl.add(x)
+    gpu_faiss.write_index(fl, str(tmp_path / "f.index"))
+    files["f"] = (tmp_path / "f.index").read_bytes()
+    ls = gpu_faiss.IndexLSH(16, 32)
+    ls.add(x)
+    gpu_faiss.write_index(ls, str(tmp_path / "l.index"))
+    files["l"] = (tmp_path / "l.index").read_bytes()
+    refused = accepted = 0
+    for name, raw in files.items():
+        cuts = sorted(set([0, 3, 4, 20, 40, 41, 45, len(raw) // 3, len(raw) // 2, len(raw) - 1] + rng.integers(0, len(raw), 25).tolist()))
+        for c in cuts:
+            p = tmp_path / "cut.index"
+            p.write_bytes(raw[:c])
+            with pytest.raises((RuntimeError, ValueError, AssertionError, struct.error)):
+                gpu_faiss.read_index(str(p))
+        for _ in range(120):
+            b = bytearray(raw)
+            # damage concentrated in the tables (the first kilobyte and around the graph's vectors), some anywhere
+            for _k in range(int(rng.integers(1, 4))):
+                pos = int(rng.integers(0, min(len(b), 2048))) if rng.integers(0, 3) else int(rng.integers(0, len(b)))
+                b[pos] = int(rng.integers(0, 256))
+            p = tmp_path / "bad.index"
+            p.write_bytes(bytes(b))
+            try:
+                idx = gpu_faiss.read_index(str(p))
+            except (RuntimeError, ValueError, AssertionError, struct.error, MemoryError, OverflowError):
+                refused += 1
+                continue
+            accepted += 1
+            if idx.ntotal and idx.d == 16:
+                D, I = idx.search(x[:4], 3)
+                assert I.shape == (4, 3) and ((I >= -1) & (I < max(idx.ntotal, 1))).all()
+    assert refused > 0 and accepted > 0
