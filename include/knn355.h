@@ -289,7 +289,8 @@ int32_t knn_scan_times(knn_handle h, float *out_ms, int32_t max_n);
 int knn_last_seed_info(knn_handle h, int32_t *seed_stride, int32_t *stat_rank, int64_t *stat_redo,
                        int64_t *sample_rows);
 /* force a scan configuration: query_tile in {0(auto),32,64,128}; nchunks 0=auto;
- * flags: 64 = always launch the state-reset kernel in front of a streaming scan (default: the previous search's
+ * flags: 256 = the two workgroups of a CU do not take turns in their K loops (batch launches),
+ * 64 = always launch the state-reset kernel in front of a streaming scan (default: the previous search's
  * final selection leaves the state reset when the next search has the same shape),
  * 32 = squared L2 by the norm formula |x|^2 + |y|^2 - 2<x,y> whatever the batch size (default: FAISS's rule --
  * batches of fewer than 20 queries use the sum of squared differences, larger ones the norm formula),
