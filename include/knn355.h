@@ -288,17 +288,23 @@ int32_t knn_scan_times(knn_handle h, float *out_ms, int32_t max_n);
  * rows scanned by the sample pass (the main scan kernel skips them) */
 int knn_last_seed_info(knn_handle h, int32_t *seed_stride, int32_t *stat_rank, int64_t *stat_redo,
                        int64_t *sample_rows);
-/* force a scan configuration: query_tile in {0(auto),32,64,128}; nchunks 0=auto;
- * flags: 256 = the two workgroups of a CU do not take turns in their K loops (batch launches),
- * 64 = always launch the state-reset kernel in front of a streaming scan (default: the previous search's
- * final selection leaves the state reset when the next search has the same shape),
- * 32 = squared L2 by the norm formula |x|^2 + |y|^2 - 2<x,y> whatever the batch size (default: FAISS's rule --
- * batches of fewer than 20 queries use the sum of squared differences, larger ones the norm formula),
- * 2 = no shared pool of tiles in a paired launch, 4 = never pair the workgroups of a one-query-tile launch (static chunks instead), 8 = no seed sample, 16 = force the exact seed, 128 = force the statistical seed
- * (synchronous entry points only), 512 = never use the statistical seed, 1024 = never use the
- * symmetric launch of a whole-index self-search, 2048 = never use the tile-minimum seed (a streaming
- * search then runs its seed sample as a launch of its own), bits 12-13 = publication rounds of the
- * tile-minimum seed (0 = the library's choice) */
+/* force a scan configuration: query_tile in {0(auto),32,64,128}; nchunks 0=auto (a forced count also turns the paired
+ * walk off); flags, all off by default:
+ *      2  no shared pool of tiles in a paired (one-query-tile) launch
+ *      4  never pair the workgroups of a one-query-tile launch: static chunks instead
+ *      8  no seeding at all (every chunk warms its thresholds up on its own)
+ *     16  force the exact seed (a sample pass of its own in front of the scan)
+ *     32  squared L2 by the norm formula |x|^2 + |y|^2 - 2<x,y> whatever the batch size (default: FAISS's rule --
+ *         batches of fewer than 20 queries use the sum of squared differences, larger ones the norm formula)
+ *     64  always launch the state-reset kernel in front of a streaming scan (default: the previous search's final
+ *         selection leaves the state reset when the next search has the same shape)
+ *    128  force the statistical seed (synchronous entry points only)
+ *    256  the two workgroups of a CU do not take turns in their K loops (batch launches)
+ *    512  never use the statistical seed
+ *   1024  never use the symmetric launch of a whole-index self-search
+ *   2048  never use the tile-minimum seed (a streaming search then runs its seed sample as a launch of its own)
+ *   bits 12-13  publication rounds of the tile-minimum seed (0 = the library's choice)
+ * Only 32 changes what a search returns (the other formula's rounding); every other combination returns the same bits. */
 int knn_set_tuning(knn_handle h, int32_t query_tile, int32_t nchunks, int32_t flags);
 
 #ifdef __cplusplus
