@@ -43,6 +43,7 @@
 #include "../../include/knn355.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef const __attribute__((address_space(1))) f32x4 *gptr4; // explicit global (not flat) loads
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -772,12 +773,13 @@ __device__ __forceinline__ void sched_spread()
 // subtract / fma chains -- thread = row of the 256-row tile (its 32 floats of the K step in registers), one chain per
 // query, the queries' floats read from LDS as broadcasts.  Behind the K loop the scores are transposed through the staging
 // buffers into the accumulator layout the MFMA would have left (lane (i, h) = query i, registers = 32 rows), so the filter,
-// the tile-minimum seed and everything else are shared.  Measured, 10 M x 1024 rows: 19.4 ms for up to 19 queries (the
-// MFMA scan with the norm formula: 7.0-7.4 ms); a build for up to 4 queries keeps a single query at its HBM time.
+// the tile-minimum seed and everything else are shared.  Two rows' chains of one query share packed fp32 instructions
+// (v_pk_add_f32 / v_pk_fma_f32).  Measured, 10 M x 1024 rows: 12.1 ms for 13-19 queries (scalar chains: 19.4; the MFMA
+// scan with the norm formula: 7.0-7.4 ms); builds for up to 12 and up to 4 queries (a single query: its HBM time).
 template <int WM, int WN, int TM, int TN, bool L2, bool NTDB = false, bool SYM = false, bool BF16 = false, int DNQ = 0>
 __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 {
-    constexpr bool DIFF = DNQ > 0; // the difference build, for batches of up to DNQ queries (4 or 20)
+    constexpr bool DIFF = DNQ > 0; // the difference build, for batches of up to DNQ queries (4, 12 or 20)
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(!DIFF || (L2 && !SYM && !BF16 && WN == 1 && TN == 1), "the difference build: one 32-query tile, squared L2");
     constexpr int DT = WM * TM * 32;        // database rows per tile
@@ -939,9 +941,9 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
         constexpr int DIFF_NQ = DIFF ? DNQ : 1; // (the difference build serves batches of fewer than 20 queries: one chain per query)
-        float dacc[DIFF_NQ];                   // ... as one chain per query and ROW = thread (see compute)
+        f32x2 dacc2[(DIFF_NQ + 1) / 2];        // ... as one chain per query and row; a thread holds two rows x half the queries (see compute)
 #pragma unroll
-        for (int qi = 0; qi < DIFF_NQ; qi++) dacc[qi] = 0.0f;
+        for (int qi = 0; qi < (DIFF_NQ + 1) / 2; qi++) dacc2[qi] = f32x2{0.0f, 0.0f};
 
         const float *tsrc[NI];
 #pragma unroll
@@ -975,31 +977,40 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
             if constexpr (DIFF) {
 #pragma unroll
                 for (int n = 0; n < ND; n++) dma(n); // (the next K step's staging goes out first: the chains below take microseconds)
-                // thread = row tid of the tile; its 32 floats of this K step, then one chain per query (the queries' floats are
-                // broadcast reads).  k = 8t + m, 8t + 4 + m, m = 0..3: the dot product's order.
-                const int rs = (tid >> 1) & 7;
-                f32x4 y[8];
+                // thread = a PAIR of rows (2 rp, 2 rp + 1) and half of the queries: the two rows' chains of one query run in
+                // the two halves of packed fp32 instructions (v_pk_add / v_pk_fma: half the vector instructions).  A pair
+                // shares its LDS swizzle, so (y0[k], y1[k]) is one ds_read2_b32; the queries' floats are broadcast reads.
+                // k = 8t + m, 8t + 4 + m, m = 0..3: the dot product's order, for either row.
+                const int rp = (wave & 1) * 64 + lane, qh = wave >> 1;
+                const char *yrow = A + (2 * rp) * 128;
+                const int rs = rp & 7; // ((2 rp) >> 1) & 7 -- the same for 2 rp + 1
+                f32x2 y[8][4];
 #pragma unroll
-                for (int sl = 0; sl < 8; sl++) y[sl] = *(const f32x4 *)(A + tid * 128 + ((sl ^ rs) * 16));
+                for (int sl = 0; sl < 8; sl++) {
+                    const float *p0 = (const float *)(yrow + ((sl ^ rs) * 16));
 #pragma unroll
-                for (int qi = 0; qi < DIFF_NQ; qi++) {
-                    const char *qrow = B + qi * 128;
-                    const int qs = (qi >> 1) & 7;
-                    float c = dacc[qi];
+                    for (int e = 0; e < 4; e++) y[sl][e] = f32x2{p0[e], p0[e + 32]};
+                }
+#pragma unroll
+                for (int qi = 0; qi < DIFF_NQ / 2; qi++) {
+                    const int q = qh * (DIFF_NQ / 2) + qi;
+                    const char *qrow = B + q * 128;
+                    const int qs = (q >> 1) & 7;
+                    f32x2 c = dacc2[qi];
 #pragma unroll
                     for (int t = 0; t < 4; t++) {
                         const f32x4 qa = *(const f32x4 *)(qrow + (((2 * t) ^ qs) * 16));
                         const f32x4 qb = *(const f32x4 *)(qrow + (((2 * t + 1) ^ qs) * 16));
 #pragma unroll
                         for (int m = 0; m < 4; m++) {
-                            const float ta = qa[m] - y[2 * t][m];
-                            c = __builtin_fmaf(ta, ta, c);
-                            const float tb = qb[m] - y[2 * t + 1][m];
-                            c = __builtin_fmaf(tb, tb, c);
+                            const f32x2 ta = f32x2{qa[m], qa[m]} - y[2 * t][m];
+                            c = __builtin_elementwise_fma(ta, ta, c);
+                            const f32x2 tb = f32x2{qb[m], qb[m]} - y[2 * t + 1][m];
+                            c = __builtin_elementwise_fma(tb, tb, c);
                         }
                     }
-                    dacc[qi] = c;
-                    if ((qi & 3) == 3) __builtin_amdgcn_sched_barrier(0); // (four queries' reads in flight, not all twenty)
+                    dacc2[qi] = c;
+                    if ((qi & 1) == 1) __builtin_amdgcn_sched_barrier(0); // (two queries' reads in flight, not all ten)
                 }
                 return;
             }
@@ -1110,8 +1121,11 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
             static_assert(DT == 256 && QT == 32, "thread = row");
             float *sT = (float *)smem; // [DIFF_NQ][DT]
             __syncthreads();           // (every wave has read its last fragments)
+            {
+                const int rp = (wave & 1) * 64 + lane, qh = wave >> 1;
 #pragma unroll
-            for (int qi = 0; qi < DIFF_NQ; qi++) sT[qi * DT + tid] = dacc[qi];
+                for (int qi = 0; qi < DIFF_NQ / 2; qi++) *(f32x2 *)(sT + (qh * (DIFF_NQ / 2) + qi) * DT + 2 * rp) = dacc2[qi];
+            }
             __syncthreads();
 #pragma unroll
             for (int a = 0; a < TM; a++)
@@ -2529,7 +2543,8 @@ static int launch_scan_cfg(const knn_index_s *h, const ScanParams &p, const Scan
     if constexpr (WM == 4 && TM == 2) {
         if (plan.diff) {
             // (a build for up to 4 queries -- a single query scans at the speed of its HBM traffic -- and one for up to 19)
-            kern = p.nq <= 4 ? flat_scan_kernel<4, 1, 2, 1, true, true, false, false, 4> : flat_scan_kernel<4, 1, 2, 1, true, true, false, false, 20>;
+            kern = p.nq <= 4 ? flat_scan_kernel<4, 1, 2, 1, true, true, false, false, 4>
+                             : (p.nq <= 12 ? flat_scan_kernel<4, 1, 2, 1, true, true, false, false, 12> : flat_scan_kernel<4, 1, 2, 1, true, true, false, false, 20>);
             HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds));
             hipLaunchKernelGGL(kern, dim3(plan.grid), dim3(256), plan.lds, s, p);
             HIP_TRY(hipGetLastError());
@@ -2689,7 +2704,10 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     if (!seed && allow_stat && level == 0 && row_mul == 1 && !(h->flags & (8 | 16 | 512))) {
         // statistical seed: single rows, every 32nd (every 16th of a small database, every 64th of a
         // large one): a few percent of the work, one round of workgroups at CATH size
-        const int st = nb >= (1 << 20) ? 64 : (nb >= 8192 ? 32 : 16);
+        int st = nb >= (1 << 20) ? 64 : (nb >= 8192 ? 32 : 16);
+#ifdef KNN355_DEV
+        if (getenv("KNN355_STAT_STRIDE")) st = atoi(getenv("KNN355_STAT_STRIDE")); // (developer build: the statistical sample's stride)
+#endif
         const bool force = (h->flags & 128) != 0;
         const int64_t S = view_rows(nb, st, 0);
         const int j = stat_seed_rank(S, nb, k);
@@ -3067,7 +3085,10 @@ static bool self_search_symmetric_eligible(const knn_index_s *h, int k, int *j_o
 {
     const int64_t n = h->ntotal;
     if (n < 8192 || k > KNN_WAVE_SELECT_MAX_K || k >= n || (h->flags & (8 | 16 | 512 | 1024)) || h->force_qt || h->force_chunks || h->approx16) return false;
-    const int st = n >= (1 << 20) ? 64 : 32;
+    int st = n >= (1 << 20) ? 64 : 32;
+#ifdef KNN355_DEV
+    if (getenv("KNN355_STAT_STRIDE")) st = atoi(getenv("KNN355_STAT_STRIDE"));
+#endif
     const int64_t S = view_rows(n, st, 0);
     const int j = stat_seed_rank(S, n, k);
     if (j <= 0) return false;
@@ -3084,7 +3105,10 @@ static int self_search_symmetric(knn_index_s *h, int k, float *D_dev, int64_t *I
     const int64_t n = h->ntotal;
     int j = 0, qcap = 0;
     if (!self_search_symmetric_eligible(h, k, &j, &qcap)) return 0;
-    const int st = n >= (1 << 20) ? 64 : 32;
+    int st = n >= (1 << 20) ? 64 : 32;
+#ifdef KNN355_DEV
+    if (getenv("KNN355_STAT_STRIDE")) st = atoi(getenv("KNN355_STAT_STRIDE"));
+#endif
     const int64_t S = view_rows(n, st, 0);
     const double expect = 1.3 * (double)j * (double)n / (double)S + 1.25 * k;
     ScanPlan pl;
