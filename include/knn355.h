@@ -304,8 +304,18 @@ int knn_last_seed_info(knn_handle h, int32_t *seed_stride, int32_t *stat_rank, i
  *   1024  never use the symmetric launch of a whole-index self-search
  *   2048  never use the tile-minimum seed (a streaming search then runs its seed sample as a launch of its own)
  *   bits 12-13  publication rounds of the tile-minimum seed (0 = the library's choice)
+ *  16384  never search the remainder behind the full 128-query tiles as a piece of its own (large databases: 129 queries
+ *         are one 128-query launch and one streaming launch instead of two 128-query passes)
  * Only 32 changes what a search returns (the other formula's rounding); every other combination returns the same bits. */
 int knn_set_tuning(knn_handle h, int32_t query_tile, int32_t nchunks, int32_t flags);
+
+/* A caller that hands one batch of queries over in pieces (its own blocks, one slice per GPU) says how large the
+ * whole batch is: FAISS chooses the squared-L2 formula by the batch ITS caller passed to index.search
+ * (/root/reference/seqvec_search/main.py:45; fewer than 20 queries: the sum of squared differences), so pieces of
+ * fewer than 20 queries of a larger batch keep the norm formula and the pieces return the bits of the one call.
+ * nq_whole = 0 (default): every call is its own batch.  The setting stays until changed; it is per handle (views made
+ * with knn_flat_view have their own). */
+int knn_flat_set_batch(knn_handle h, int64_t nq_whole);
 
 #ifdef __cplusplus
 }

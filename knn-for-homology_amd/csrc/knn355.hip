@@ -2023,6 +2023,8 @@ struct knn_index_s {
     int *flag_host = nullptr;     // pinned: [slot] copy of ws_flag behind each batch of a host search
     // tuning + introspection
     int force_qt = 0, force_chunks = 0, flags = 0;
+    int64_t batch_nq = 0; // the caller's whole batch while a search works through it in pieces (BatchScope); 0: outside a search
+    int64_t batch_hint = 0; // knn_flat_set_batch: the calls that follow are pieces of a batch of this many queries (0: each its own)
     int pub_rounds_force = 0; // tile-minimum seed: rounds of publications (0: the host's choice)
     std::string last_kernel;
     int last_qt = 0, last_dt = 0, last_chunks = 0, last_grid = 0;
@@ -2566,11 +2568,14 @@ static void make_plan(const knn_index_s *h, int64_t nb, int64_t nq, int k, bool 
 {
     int qt = h->force_qt;
     if (qt != 32 && qt != 64 && qt != 128) qt = nq <= 32 ? 32 : (nq <= 64 ? 64 : 128);
-    if (h->metric == KNN_METRIC_L2 && nq < 20 && !h->approx16 && !(h->flags & 32)) qt = 32; // (the difference build exists for the 32-query tile only)
+    // FAISS's squared L2 for fewer than 20 queries: the sum of squared differences (flags & 32: the norm formula throughout).
+    // FAISS decides on the batch its caller handed over, so a piece of a larger batch (the last block of 16384 queries, the
+    // remainder behind the full query tiles) keeps the formula of the whole.
+    const bool small_batch = (h->batch_nq ? h->batch_nq : nq) < 20 && nq < 20;
+    if (h->metric == KNN_METRIC_L2 && small_batch && !h->approx16 && !(h->flags & 32)) qt = 32; // (the difference build exists for the 32-query tile only)
     pl.qt = qt;
     pl.dt = qt == 32 ? 256 : 128;
-    // FAISS's squared L2 for fewer than 20 queries: the sum of squared differences (flags & 32: the norm formula throughout)
-    pl.diff = h->metric == KNN_METRIC_L2 && nq < 20 && qt == 32 && !h->approx16 && !(h->flags & 32);
+    pl.diff = h->metric == KNN_METRIC_L2 && small_batch && qt == 32 && !h->approx16 && !(h->flags & 32);
     pl.name = pl.diff ? "flat_scan_q32_d256_l2diff" : (qt == 128 ? "flat_scan_q128_d128" : (qt == 64 ? "flat_scan_q64_d128" : "flat_scan_q32_d256"));
     pl.nqtiles = (int)((nq + qt - 1) / qt);
     pl.cap = next_pow2_host(2 * k + pl.dt);
@@ -2912,9 +2917,21 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
 // queries [nq][dp] already on device (padded); writes sorted keys [nq][k] and/or D/I.
 // allow_stat: the caller reads the fail flag once the stream has drained (search_failed) and repeats
 // the search with allow_stat = false if it is set.
+// The batch a caller handed over, for as long as the search works through it in pieces (the outermost scope wins).
+struct BatchScope {
+    knn_index_s *h;
+    int64_t prev;
+    BatchScope(knn_index_s *h_, int64_t nq) : h(h_), prev(h_->batch_nq)
+    {
+        if (!prev) h->batch_nq = h->batch_hint > 0 ? std::max(nq, h->batch_hint) : nq;
+    }
+    ~BatchScope() { h->batch_nq = prev; }
+};
+
 static int search_keys_impl(knn_index_s *h, const float *q_dev, int64_t nq, int k, uint32_t id_base,
                             uint64_t *keys_out, float *D_out, int64_t *I_out, bool allow_stat, hipStream_t s)
 {
+    BatchScope scope(h, nq);
     const float *xn = nullptr;
     if (h->metric == KNN_METRIC_L2) {
         if (h->ws_qn.ensure((size_t)nq * 4, h->done, s)) return set_err(KNN_ERR_HIP, "search: out of device memory");
@@ -2939,8 +2956,34 @@ static int search_keys_impl(knn_index_s *h, const float *q_dev, int64_t nq, int 
     // verification flag of a statistically seeded search is cleared by the first block only: it accumulates.
     const int64_t QB = 16384;
     const int64_t nblocks = nq > QB + QB / 2 ? (nq + QB - 1) / QB : 1;
+    // The remainder behind the full 128-query tiles.  A query tile costs its whole width whatever it holds: on a database
+    // that is streamed from HBM 129 queries took two passes of the 128-query build (10 M rows: 39.2 ms; 128 queries: 20.9).
+    // The remainder is searched on its own with the narrowest build that holds it -- <= 32 queries: the streaming build
+    // (7.1 ms per 10 M rows), <= 64: the 64-query build (11.6), a batch of 65..96: both (18.4-18.9 ms against 20.2-20.5 for
+    // one 128-query pass).  Queries are independent, so the pieces return what one launch would.  Small databases keep one launch (the
+    // pieces' own seeds and selections cost more than a padded tile saves).
+    struct Piece {
+        int64_t q0, m;
+    };
+    std::vector<Piece> pieces;
+    const bool split = h->ntotal >= (1 << 18) && !h->force_qt && !(h->flags & 16384);
     for (int64_t b = 0; b < nblocks; b++) {
         const int64_t q0 = b * QB, m = nblocks == 1 ? nq : std::min(QB, nq - q0);
+        const int64_t full = m / 128 * 128, r = m - full;
+        if (!split || m <= 64 || r == 0 || r > 96 || (r > 64 && full)) { // (65..96 behind full tiles: the two narrow passes cost what the padded tile does)
+            pieces.push_back({q0, m});
+            continue;
+        }
+        if (full) pieces.push_back({q0, full});
+        if (r > 64) {
+            pieces.push_back({q0 + full, 64});
+            pieces.push_back({q0 + full + 64, r - 64});
+        } else {
+            pieces.push_back({q0 + full, r});
+        }
+    }
+    for (size_t b = 0; b < pieces.size(); b++) {
+        const int64_t q0 = pieces[b].q0, m = pieces[b].m;
         SearchOut out;
         out.keys = keys_out ? keys_out + q0 * k : nullptr; out.keys_stride = k; out.keys_fill = 0;
         out.D = D_out ? D_out + q0 * k : nullptr; out.I = I_out ? I_out + q0 * k : nullptr;
@@ -3239,6 +3282,7 @@ static int host_search(knn_index_s *h, const float *q_host, int64_t self_row0, i
                        int64_t *I_host)
 {
     int rc = 0;
+    BatchScope scope(h, nq);
     HIP_TRY(hipSetDevice(h->device));
     // Query batches bound the device workspace; 16384 queries keep >= 128 query tiles in flight.
     // Batches are pipelined: while batch b is scanned, a helper thread downloads the results of
@@ -3457,6 +3501,7 @@ extern "C" int knn_flat_search_self_dev(knn_handle h, int64_t k, float *D_dev, i
         if (!failed) return 0;
     }
     const int64_t QB = 16384;
+    BatchScope scope(h, h->ntotal);
     for (int64_t b0 = 0; b0 < h->ntotal; b0 += QB) {
         const int64_t m = std::min(QB, h->ntotal - b0);
         for (int attempt = 0; attempt < 2; attempt++) { // (statistical seed first, plain if its verification fails)
@@ -3605,6 +3650,15 @@ extern "C" int knn_set_tuning(knn_handle h, int32_t query_tile, int32_t nchunks,
     h->force_chunks = nchunks;
     h->flags = flags & ~(3 << 12);
     h->pub_rounds_force = (flags >> 12) & 3; // bits 12-13: publication rounds of the tile-minimum seed (0: the host's choice)
+    return 0;
+}
+
+extern "C" int knn_flat_set_batch(knn_handle h, int64_t nq_whole)
+{
+    if (!h) return set_err(KNN_ERR_INVALID, "null handle");
+    if (nq_whole < 0) return set_err(KNN_ERR_INVALID, "set_batch: negative batch size");
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->batch_hint = nq_whole;
     return 0;
 }
 

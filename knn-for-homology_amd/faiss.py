@@ -148,6 +148,11 @@ class IndexFlat(Index):
     def set_tuning(self, query_tile=0, nchunks=0, flags=0):
         _lib.check(_lib.lib().knn_set_tuning(self._h, query_tile, nchunks, flags))
 
+    def set_batch(self, nq_whole=0):
+        """The searches that follow are pieces of one batch of ``nq_whole`` queries (0: each call is its own batch):
+        FAISS picks the squared-L2 formula by the size of the batch handed to ``index.search``."""
+        _lib.check(_lib.lib().knn_flat_set_batch(self._h, int(nq_whole)))
+
     def last_scan(self):
         L = _lib.lib()
         name = ctypes.create_string_buffer(64)

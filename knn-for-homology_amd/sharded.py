@@ -273,7 +273,15 @@ class QueryShardedFlatIndex:
         nq = q.shape[0]
         lo, hi = self.query_bounds(nq)
         if hi > lo:
-            D, I = self.backend.search(q[lo:hi].contiguous(), k)
+            # (this rank's slice is a piece of the caller's batch: the L2 formula FAISS would pick for all nq queries)
+            set_batch = getattr(getattr(self.backend, "index", None), "set_batch", None)
+            if set_batch:
+                set_batch(nq)
+            try:
+                D, I = self.backend.search(q[lo:hi].contiguous(), k)
+            finally:
+                if set_batch:
+                    set_batch(0)
         else:
             D = torch.empty((0, k), dtype=torch.float32, device=q.device)
             I = torch.empty((0, k), dtype=torch.int64, device=q.device)

@@ -862,3 +862,69 @@ def test_normalize_l2_in_chunks_matches_oracle(gpu_faiss, oracle):
     gpu_faiss.normalize_L2(held)
     assert held is x and np.array_equal(x.view(np.uint32), want.view(np.uint32))
     assert not x[123].any() and not x[-1].any()
+
+
+@pytest.mark.gpu
+def test_l2_formula_follows_the_whole_batch_not_its_pieces(gpu_faiss, oracle):
+    """FAISS picks the squared-L2 formula by the batch handed to index.search (fewer than 20 queries: differences).  The
+    library works through a large batch in blocks of 16384 queries: a last block of fewer than 20 must keep the norm
+    formula of the whole; knn_flat_set_batch lets a caller that splits its batch itself say the same."""
+    rng = np.random.default_rng(16389)
+    nb, d, k = 400, 40, 6
+    xb = rng.standard_normal((nb, d), dtype=np.float32)
+    xq = rng.standard_normal((3 * 16384 + 5, d), dtype=np.float32)  # (host blocks of 16384: the last one has 5 queries)
+    idx = gpu_faiss.IndexFlat(d, 1)
+    idx.add(xb)
+    D, I = idx.search(xq, k)
+    _assert_same(D, I, *oracle.flat_search(xb, xq, k, 1))
+    # the same five queries as a batch of their own: the other formula
+    D5, I5 = idx.search(xq[-5:], k)
+    assert idx.last_scan()["kernel"].endswith("l2diff")
+    _assert_same(D5, I5, *oracle.flat_search(xb, xq[-5:], k, 1))
+    assert (D5.view(np.uint32) != D[-5:].view(np.uint32)).any()
+    # ... and as a declared piece of a batch of 40: the norm formula again
+    idx.set_batch(40)
+    Dp, Ip = idx.search(xq[-5:], k)
+    assert not idx.last_scan()["kernel"].endswith("l2diff")
+    _assert_same(Dp, Ip, *oracle.flat_search(xb, xq[-5:], k, 1, l2_mode=1))
+    idx.set_batch(0)
+    Dq, Iq = idx.search(xq[-5:], k)
+    _assert_same(Dq, Iq, D5, I5)
+    # whole-index self-search in blocks (symmetric launch off): 16384 + 7 rows
+    xs = rng.standard_normal((16384 + 7, 24), dtype=np.float32)
+    s = gpu_faiss.IndexFlat(24, 1)
+    s.add(xs)
+    s.set_tuning(0, 0, 1024)
+    Ds, Is = s.search_self(4)
+    Do, Io = oracle.flat_search(xs, xs[-40:], 4, 1)
+    _assert_same(Ds[-40:], Is[-40:], Do, Io)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric", [0, 1])
+def test_remainder_behind_the_full_query_tiles_is_searched_on_its_own(gpu_faiss, oracle, metric):
+    """On a database that is streamed from HBM the queries behind the last full 128-query tile are searched with the
+    narrowest build that holds them (<= 32: streaming build, <= 64: 64-query build; a batch of 65..96: both) instead of a padded
+    128-query tile.  Same bits as one launch (flags 16384) and as the oracle, whatever the split."""
+    rng = np.random.default_rng(129 + metric)
+    nb, d, k = 300_000, 32, 20
+    xb = rng.standard_normal((nb, d), dtype=np.float32)
+    xb[5000:5050] = xb[:50]
+    idx = gpu_faiss.IndexFlat(d, metric)
+    idx.add(xb)
+    for nq in (129, 150, 161, 200, 96, 70, 64, 128, 257, 353):
+        xq = rng.standard_normal((nq, d), dtype=np.float32)
+        xq[-1] = xb[17]
+        idx.set_tuning(0, 0, 0)
+        D, I = idx.search(xq, k)
+        last = idx.last_scan()["kernel"]
+        r = nq % 128
+        if nq > 64 and (0 < r <= 64 or nq < 128 and r <= 96):
+            assert last == ("flat_scan_q64_d128" if 32 < r <= 64 else "flat_scan_q32_d256"), (nq, last)
+        else:
+            assert last == ("flat_scan_q128_d128" if nq > 64 else "flat_scan_q64_d128"), (nq, last)
+        idx.set_tuning(0, 0, 16384)
+        D1, I1 = idx.search(xq, k)
+        assert idx.last_scan()["kernel"] == ("flat_scan_q128_d128" if nq > 64 else "flat_scan_q64_d128")
+        _assert_same(D, I, D1, I1)
+        _assert_same(D, I, *oracle.flat_search(xb, xq, k, metric))
