@@ -281,8 +281,9 @@ float knn_last_scan_ms(knn_handle h);
 int32_t knn_scan_times(knn_handle h, float *out_ms, int32_t max_n);
 /* how the last search on this handle was seeded: seed_stride = 0 (no seed sample), the
  * stride of the sample searched first, or -r (tile-minimum seed: no sample pass, every chunk of the
- * scan publishes the best key of each of its first r tiles and the k-th smallest published key
- * is the bound); stat_rank = 0 (the sample's k-th score, a proven bound)
+ * scan publishes r keys per query -- the best key of each of its first r tiles (r = 1, 2) or, for a k beyond
+ * what that supports, the best key of each wave's rows of the first tile (r = 4 with the 32-query tile, 2 with the
+ * 64-query tile) -- and the k-th smallest published key is the bound); stat_rank = 0 (the sample's k-th score, a proven bound)
  * or j (statistical seed: the sample's j-th score, result verified); stat_redo = searches
  * repeated so far because a statistical threshold failed its verification; sample_rows =
  * rows scanned by the sample pass (the main scan kernel skips them) */

@@ -522,6 +522,7 @@ struct ScanParams {
     uint64_t *pub;     // [nqtiles*QT][pub_n], pub_n = pub_rounds * nchunks, KEY_PAD = not published yet; NULL: off
     uint32_t *arrive;  // [nqtiles] publications so far
     int pub_n, pub_rounds;
+    int pub_m;         // keys a workgroup publishes per query and round: 1 (the tile's best) or WM (each wave's best of its own rows)
     float *defer;      // [grid][QT * DT] the parked scores of every workgroup's first tile
     // paired workgroups (one-query-tile launches): workgroups w and w + npairs share ONE range of tiles, w walks it from
     // the front, w + npairs from the back; every tile is claimed with a ticket (see flat_scan_kernel)
@@ -1259,12 +1260,20 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
                     const uint32_t olo = (uint32_t)__shfl_xor((int)(uint32_t)best, 32);
                     const uint64_t other = ((uint64_t)ohi << 32) | olo;
                     best = other < best ? other : best;
-                    if (lh == 0 && q < p.nq) atomicMin((unsigned long long *)&s_pub[ql], (unsigned long long)best);
+                    if (p.pub_m > 1) {
+                        // every wave publishes the best key of ITS rows (WM keys of WM different rows per workgroup and query):
+                        // enough publications for a k beyond the number of workgroups
+                        if (lh == 0 && q < p.nq)
+                            __hip_atomic_store(&p.pub[(size_t)q * p.pub_n + ((size_t)tile_idx * p.nchunks + (paired ? (int)blockIdx.x : chunk)) * WM + wm], best,
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else if (lh == 0 && q < p.nq) {
+                        atomicMin((unsigned long long *)&s_pub[ql], (unsigned long long)best);
+                    }
                 }
                 deferred = tile_idx == 0;
                 __syncthreads();
                 if (wave == 0) {
-                    if (lane < QT) {
+                    if (lane < QT && p.pub_m == 1) {
                         if (q0 + lane < p.nq)
                             __hip_atomic_store(&p.pub[(size_t)(q0 + lane) * p.pub_n + (size_t)tile_idx * p.nchunks + (paired ? (int)blockIdx.x : chunk)], s_pub[lane],
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1279,7 +1288,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
                     // arrivals take the queries in turn: from the (k + QT)-th on every query has a bound, the last QT
                     // arrivals of a round see (almost) every publication
                     const int ql = a % QT;
-                    if (q0 + ql < p.nq && a + 1 >= p.k) {
+                    if (q0 + ql < p.nq && (a + 1) * p.pub_m >= p.k) {
                         uint32_t T = 0xFFFFFFFFu;
                         const int kmax = p.k + max(p.k >> 2, 32);
                         wave_select_dispatch((p.pub_n + 63) >> 6, LoadAgent{p.pub + (size_t)(q0 + ql) * p.pub_n}, p.pub_n, p.k, kmax, lane, &T,
@@ -2741,19 +2750,37 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     // chunks seeds itself -- each chunk publishes its first tiles' best key per query, the k-th smallest published key
     // is the bound.  Needs: the 32- or 64-query tile, plain fp32 rows, a few times k publications that fit one wave's
     // registers (<= 2048), chunks long enough that an unfiltered first tile is noise.  flags & 2048: never.
-    int pub_rounds = 0;
-    if (seed && !(h->flags & (16 | 2048)) && !h->approx16 && pl.qt <= 64 && pl.cap >= 2 * pl.dt && pl.tiles_base >= (pl.npairs ? 8 : 4)) {
+    int pub_rounds = 0, pub_m = 1;
+    const bool pub_shape = !(h->flags & (8 | 16 | 128 | 2048)) && !h->approx16 && pl.qt <= 64 && pl.cap >= 2 * pl.dt && pl.tiles_base >= (pl.npairs ? 8 : 4);
+    if (seed && pub_shape) {
         for (int r = 2; r >= 1; r--) // (one round if it gives enough publications)
             if ((int64_t)r * pl.nchunks <= 2048 && (int64_t)r * pl.nchunks >= 2 * (int64_t)k + 64 && r < pl.tiles_base) pub_rounds = r;
         if (h->pub_rounds_force > 0 && (int64_t)h->pub_rounds_force * pl.nchunks <= 2048 && h->pub_rounds_force < pl.tiles_base &&
             (int64_t)h->pub_rounds_force * pl.nchunks >= (int64_t)k + 32)
             pub_rounds = h->pub_rounds_force;
     }
+    if (!pub_rounds && pub_shape && !h->pub_rounds_force && nb >= 16 * (int64_t)k && k <= KNN_WAVE_SELECT_MAX_K) {
+        // A k beyond what one key per workgroup supports (512 workgroups, two rounds: k <= 480): every WAVE publishes the
+        // best key of its own rows of the first tile -- 4 keys per workgroup and query with the 32-query tile, 2 with the
+        // 64-query one, all of different rows, no reduction across the waves.  The k-th smallest of P such keys sits near the
+        // -P ln(1 - k / P) / (P x rows per wave) quantile (k = 1000, P = 2048: 1372 of 131 k sampled rows; 2 M rows x 32
+        // queries: 2.30 ms unseeded -- every workgroup warming up its own 1000 best -- against 1.45 at k = 100).
+        const int wm = pl.qt == 32 ? 4 : 2;
+        const int64_t P = (int64_t)wm * pl.nchunks;
+        if (P <= 2048 && P >= (int64_t)k + k / 4 + 32 && pl.tiles_base > 1) {
+            pub_rounds = 1;
+            pub_m = wm;
+        }
+    }
     if (pub_rounds) {
         sstride = 0;
         // the bound sits near the k / (publications x tile rows) quantile; the first tile(s) of every chunk are filtered
         // again at the end of the chunk
         expect_n = 2.0 * (double)k * (double)nb / ((double)pub_rounds * pl.nchunks * pl.dt) + 2.0 * k + 64;
+        if (pub_m > 1) {
+            const double P = (double)pub_m * pl.nchunks;
+            expect_n = 1.3 * (-P * log(1.0 - (double)k / P)) * (double)nb / ((double)pl.nchunks * pl.dt) + 2.0 * k + 64;
+        }
     }
     if (!sstride && !pub_rounds) make_plan(h, nb, nq, k, level > 0, pl, allow_pairs && level == 0); // a seed sample is small: parallelism over warm-up
     // Most keys a chunk hands on per query.  Chunks of a single tile (a seed sample, a tiny database)
@@ -2787,7 +2814,7 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
         const int64_t nn = std::max<int64_t>((int64_t)nslots, nq);
         uint64_t *pub = nullptr;
         uint32_t *arrive = nullptr;
-        const int64_t npub = (int64_t)nslots * pub_rounds * pl.nchunks;
+        const int64_t npub = (int64_t)nslots * pub_rounds * pl.nchunks * pub_m;
         if (pub_rounds) {
             if (lb.pub.ensure((size_t)npub * 8, h->done, s) || lb.arrive.ensure((size_t)pl.nqtiles * 4, h->done, s)) return set_err(KNN_ERR_HIP, "search: out of device memory");
             pub = (uint64_t *)lb.pub.p;
@@ -2836,7 +2863,8 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     p.pub = pub_rounds ? (uint64_t *)lb.pub.p : nullptr;
     p.arrive = pub_rounds ? (uint32_t *)lb.arrive.p : nullptr;
     p.pub_rounds = pub_rounds;
-    p.pub_n = pub_rounds * pl.nchunks;
+    p.pub_n = pub_rounds * pl.nchunks * pub_m;
+    p.pub_m = pub_m;
     p.pair_ctr = pl.npairs ? (uint32_t *)lb.pair_ctr.p : nullptr;
     p.npairs = pl.npairs;
     if (pl.nqtiles > 1 && !h->approx16 && pl.tiles_base >= 2 && !(h->flags & 256)) { // (turn taking: batch launches with real chunks)
@@ -2882,7 +2910,7 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     if (top) {
         HIP_TRY(hipEventRecord(h->ev1, s));
         h->last_kernel = pl.name; h->last_qt = pl.qt; h->last_dt = pl.dt; h->last_chunks = pl.nchunks; h->last_grid = pl.grid;
-        h->last_seed_stride = pub_rounds ? -pub_rounds : sstride; // (negative: tile-minimum seed with that many rounds)
+        h->last_seed_stride = pub_rounds ? -pub_rounds * pub_m : sstride; // (negative: tile-minimum seed, keys per workgroup and query)
         h->last_seed_stat = seed_stat ? seed_j : 0;
         h->last_sample_rows = sstride ? view_rows(nb, sstride, p.vshift) : 0;
     }
@@ -2904,7 +2932,7 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     sp.qthr = qthr; sp.fail = (int *)h->ws_flag.p;
     if (reset_sig && out.seed_cnt == nullptr) {
         sp.rs_gthr = gthr; sp.rs_qcnt = qcnt; sp.rs_qthr = qthr; sp.rs_nslots = (int)nslots;
-        sp.rs_pub = (uint64_t *)lb.pub.p; sp.rs_pub_n = pub_rounds * pl.nchunks;
+        sp.rs_pub = (uint64_t *)lb.pub.p; sp.rs_pub_n = pub_rounds * pl.nchunks * pub_m;
         sp.rs_arrive = (uint32_t *)lb.arrive.p; sp.rs_narrive = pl.nqtiles;
         sp.rs_pair = (uint32_t *)lb.pair_ctr.p; sp.rs_npairs = pl.npairs;
     }

@@ -772,6 +772,49 @@ def test_tile_minimum_seed_with_adversarial_order(gpu_faiss, oracle):
     _assert_same(D, I, *oracle.flat_search(xb, xq, k, 0))
 
 
+@pytest.mark.parametrize("metric,nb,d,nq,k,keys", [(0, 620_000, 32, 32, 1000, 4), (1, 620_000, 32, 7, 600, 4), (0, 560_000, 24, 32, 1536, 4),
+                                                   (1, 620_000, 32, 48, 600, 2), (0, 620_000, 32, 64, 700, 2), (1, 600_000, 40, 21, 481, 4)])
+def test_tile_minimum_seed_with_one_key_per_wave_for_large_k(gpu_faiss, oracle, metric, nb, d, nq, k, keys):
+    """k beyond the number of workgroups (two rounds of 512 publications carry k <= 480): every wave publishes the best
+    key of its own rows of the first tile (4 per workgroup and query with the 32-query tile, 2 with the 64-query one).
+    Same bits as the oracle and as the build without the tile-minimum seed, duplicates and ties included."""
+    rng = np.random.default_rng(nb + k + nq)
+    xb = rng.standard_normal((nb, d), dtype=np.float32)
+    xb[nb // 2: nb // 2 + 700] = xb[:700]
+    xb[-90:] = 0.0
+    xq = np.concatenate([rng.standard_normal((max(nq - 2, 0), d), dtype=np.float32), xb[:min(2, nq)]])[:nq]
+    idx = gpu_faiss.IndexFlat(d, metric)
+    idx.add(xb)
+    D, I = idx.search(xq, k)
+    assert idx.last_seed()["stride"] == -keys, (idx.last_seed(), idx.last_scan())
+    Do, Io = oracle.flat_search(xb, xq, k, metric)
+    _assert_same(D, I, Do, Io)
+    D1, I1 = idx.search(xq, k)  # (back to back: the state the first search's selection left)
+    _assert_same(D1, I1, Do, Io)
+    idx.set_tuning(0, 0, 2048)
+    D2, I2 = idx.search(xq, k)
+    assert idx.last_seed()["stride"] >= 0
+    _assert_same(D2, I2, Do, Io)
+
+
+def test_per_wave_publications_with_adversarial_order(gpu_faiss, oracle):
+    """every chunk's first tile holds its worst rows, the best rows of the database sit at its end: a loose bound, never a
+    wrong one (k = 1000, four keys per workgroup)"""
+    rng = np.random.default_rng(6)
+    nb, d, nq, k = 640_000, 48, 32, 1000
+    base = rng.standard_normal(d).astype(np.float32)
+    base /= np.linalg.norm(base)
+    scale = np.linspace(0.05, 2.0, nb, dtype=np.float32)
+    xb = (scale[:, None] * base[None, :] + 0.01 * rng.standard_normal((nb, d)).astype(np.float32)).astype(np.float32)
+    xq = (base[None, :] + 0.01 * rng.standard_normal((nq, d)).astype(np.float32)).astype(np.float32)
+    for order in (1, -1):
+        idx = gpu_faiss.IndexFlat(d, 0)
+        idx.add(np.ascontiguousarray(xb[::order]))
+        D, I = idx.search(xq, k)
+        assert idx.last_seed()["stride"] == -4
+        _assert_same(D, I, *oracle.flat_search(np.ascontiguousarray(xb[::order]), xq, k, 0))
+
+
 # ---- FAISS's small-batch squared L2: the sum of squared differences (round 3) --------------------------------------
 @pytest.mark.parametrize("nb,d,nq,k", [(1000, 5, 1, 3), (5000, 64, 7, 10), (4097, 100, 19, 50), (300, 1024, 6, 11),
                                        (20000, 33, 19, 100), (600_000, 32, 5, 10), (700_001, 16, 19, 100)])
