@@ -20,7 +20,7 @@ from typing import Optional, Tuple
 import numpy
 from numpy import ndarray
 
-from .. import faiss
+from .. import faiss, ranks
 from ..paths import cath_data as _default_cath_data
 
 _METRICS = (("Cosine", faiss.METRIC_INNER_PRODUCT), ("Euclidean", faiss.METRIC_L2))
@@ -31,7 +31,8 @@ def search(embeddings: ndarray, hits: int = 10, metric=faiss.METRIC_INNER_PRODUC
     # a private copy on the host, so the caller's array is left alone either way) and then
     # serve as their own queries.  Same bits as normalize_L2 + add + search on the host arrays
     # (tests/test_flat_gpu.py::test_search_self_equals_host_path).
-    index = faiss.IndexFlat(embeddings.shape[1], metric)
+    # (under a torch.distributed launch: every rank holds the rows and answers its slice of them, see ranks.py)
+    index = ranks.flat_index(embeddings.shape[1], metric)
     if metric == faiss.METRIC_INNER_PRODUCT:
         index.add(numpy.ascontiguousarray(embeddings))  # the reference's .copy() also makes it contiguous
         index.normalize_rows()
@@ -43,19 +44,23 @@ def search(embeddings: ndarray, hits: int = 10, metric=faiss.METRIC_INNER_PRODUC
 
 def search_and_save(cath_data: Optional[Path] = None):
     data_dir = Path(cath_data) if cath_data is not None else _default_cath_data()
+    say = print if ranks.writer() else (lambda *a, **k: None)  # (multi-rank launch: rank 0 prints and writes)
     for label, metric in _METRICS:
-        print(f"Searching with {label}")
+        say(f"Searching with {label}")
         all_hits, all_scores = {}, {}
         for npy in sorted(data_dir.glob("*.npy")):
             embeddings = numpy.load(npy).astype(numpy.float32)
-            print(npy.stem, embeddings.shape)
+            say(npy.stem, embeddings.shape)
             t0 = time.time()
             all_hits[npy.stem], all_scores[npy.stem] = search(embeddings, metric=metric)
             elapsed = time.time() - t0
-            print(elapsed)
-            npy.with_suffix(f".{label.lower()}-search-time.txt").write_text(str(elapsed))
-        numpy.savez(data_dir / f"hits_{label.lower()}.npz", **all_hits)
-        numpy.savez(data_dir / f"scores_{label.lower()}.npz", **all_scores)
+            say(elapsed)
+            if ranks.writer():
+                npy.with_suffix(f".{label.lower()}-search-time.txt").write_text(str(elapsed))
+        if ranks.writer():
+            numpy.savez(data_dir / f"hits_{label.lower()}.npz", **all_hits)
+            numpy.savez(data_dir / f"scores_{label.lower()}.npz", **all_scores)
+        ranks.barrier()  # (the files exist when any rank returns)
 
 
 if __name__ == "__main__":

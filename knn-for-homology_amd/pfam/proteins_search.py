@@ -19,7 +19,7 @@ from typing import Optional, Sequence
 
 import numpy
 
-from .. import faiss
+from .. import faiss, ranks
 from ..paths import full_sequences_data as _default_dir
 
 K = 1000
@@ -46,7 +46,7 @@ def naturalsize(nbytes: int) -> str:
 
 def build_index(index_mode: str, d: int):
     if index_mode == "flat":
-        return faiss.IndexFlat(d, faiss.METRIC_INNER_PRODUCT)
+        return ranks.flat_index(d, faiss.METRIC_INNER_PRODUCT)  # (one GPU: faiss.IndexFlat; multi-rank launch: query-sharded)
     if index_mode == "lsh":
         return faiss.IndexLSH(d, LSH_BITS)
     if index_mode == "hnsw":
@@ -59,6 +59,18 @@ def build_index(index_mode: str, d: int):
 def run(embeddings: numpy.ndarray, index_mode: str, data_dir: Path, npy_size: int, k: int = K):
     """pfam/proteins_search.py:21-57 on an array already loaded and cast: normalises ``embeddings`` IN PLACE
     (:22 ``faiss.normalize_L2(embeddings)``), builds / writes the index, searches, saves."""
+    if index_mode != "flat" and ranks.launched_group()[1] > 1:
+        # HNSW and LSH do not shard (SURVEY.md 8(e): replicas only): under a multi-rank launch rank 0 runs them on its
+        # GPU, the other ranks wait for its files
+        result = None
+        if ranks.writer():
+            result = _run(embeddings, index_mode, data_dir, npy_size, k, print, lambda: None)
+        ranks.barrier()
+        return result
+    return _run(embeddings, index_mode, data_dir, npy_size, k, print if ranks.writer() else (lambda *a, **kw: None), ranks.barrier)
+
+
+def _run(embeddings, index_mode, data_dir, npy_size, k, say, barrier):
     started = time()
     index = build_index(index_mode, embeddings.shape[1])
     if index_mode == "flat":
@@ -73,14 +85,16 @@ def run(embeddings: numpy.ndarray, index_mode: str, data_dir: Path, npy_size: in
         faiss.normalize_L2(embeddings)
         index.train(embeddings)
         index.add(embeddings)
-    print(f"Index creation took {int(time() - started)}s")
+    say(f"Index creation took {int(time() - started)}s")
     index_file = data_dir / f"full_sequences_{index_mode}.index"
-    if index_mode in ("flat", "hnsw"):
-        faiss.write_index(index, str(index_file), rows=embeddings)  # (the rows are still here: no second download)
-    else:
-        faiss.write_index(index, str(index_file))
+    if ranks.writer():
+        if index_mode in ("flat", "hnsw"):
+            faiss.write_index(getattr(index, "replica", index), str(index_file), rows=embeddings)  # (the rows are still here: no second download)
+        else:
+            faiss.write_index(index, str(index_file))
+    barrier()
     index_size = index_file.stat().st_size
-    print(f"Embeddings: {naturalsize(npy_size)} Index: {naturalsize(index_size)} "
+    say(f"Embeddings: {naturalsize(npy_size)} Index: {naturalsize(index_size)} "
           f"Difference: {naturalsize(index_size - npy_size)}")
 
     started = time()
@@ -89,9 +103,11 @@ def run(embeddings: numpy.ndarray, index_mode: str, data_dir: Path, npy_size: in
         scores, hits = index.search_self(k)
     else:
         scores, hits = index.search(embeddings, k)
-    print(f"Search took {int(time() - started)}s")
-    numpy.save(data_dir / f"full_sequences_{index_mode}_scores.npy", scores)
-    numpy.save(data_dir / f"full_sequences_{index_mode}_hits.npy", hits)
+    say(f"Search took {int(time() - started)}s")
+    if ranks.writer():
+        numpy.save(data_dir / f"full_sequences_{index_mode}_scores.npy", scores)
+        numpy.save(data_dir / f"full_sequences_{index_mode}_hits.npy", hits)
+    barrier()
     return scores, hits
 
 
@@ -101,7 +117,8 @@ def main(argv: Optional[Sequence[str]] = None, data_dir: Optional[Path] = None, 
     data_dir = Path(data_dir) if data_dir is not None else _default_dir()
     npy = data_dir / "full_sequences.npy"
     embeddings = numpy.load(npy).astype(numpy.float32)
-    print("full_sequences", embeddings.shape)
+    if ranks.writer():
+        print("full_sequences", embeddings.shape)
     run(embeddings, index_mode, data_dir, npy.stat().st_size, k)
 
 

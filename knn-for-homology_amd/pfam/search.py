@@ -11,7 +11,7 @@ from pathlib import Path
 
 import numpy
 
-from .. import faiss
+from .. import faiss, ranks
 from ..paths import subset10, subset10_t5
 
 K = 1000
@@ -39,11 +39,16 @@ def _filled(index, rows):
 def _search_and_store(folder: Path, stem: str, index, queries, k: int):
     """``<stem>_scores.npy`` / ``<stem>_hits.npy`` in the embedding set's directory."""
     scores, hits = index.search(queries, k)
-    for suffix, array in (("scores", scores), ("hits", hits)):
-        numpy.save(folder / f"{stem}_{suffix}.npy", array)
+    if ranks.writer():  # (multi-rank launch: every rank has the gathered arrays, rank 0 writes them)
+        for suffix, array in (("scores", scores), ("hits", hits)):
+            numpy.save(folder / f"{stem}_{suffix}.npy", array)
+    ranks.barrier()
 
 
 def search_index(embedding_set: Path, k: int = K):
+    if not ranks.writer():  # (LSH does not shard: rank 0 of a multi-rank launch runs it alone)
+        ranks.barrier()
+        return
     folder = Path(embedding_set)
     train, test = load_embeddings(folder)
     cached = folder / f"index_lsh_{LSH_BITS}.bin"
@@ -58,14 +63,15 @@ def search_index(embedding_set: Path, k: int = K):
 def search_flat(embedding_set: Path, k: int = K):
     folder = Path(embedding_set)
     train, test = load_embeddings(folder)
-    flat = _filled(faiss.IndexFlat(train.shape[1], faiss.METRIC_INNER_PRODUCT), train)
+    flat = _filled(ranks.flat_index(train.shape[1], faiss.METRIC_INNER_PRODUCT), train)  # (multi-rank launch: the test rows are split over the ranks)
     _search_and_store(folder, "flat", flat, test, k)
 
 
 def main():
     for embedding_set in (subset10_t5(), subset10()):
         for label, run in (("index", search_index), ("flat", search_flat)):
-            print(embedding_set, label)
+            if ranks.writer():
+                print(embedding_set, label)
             run(embedding_set)
 
 

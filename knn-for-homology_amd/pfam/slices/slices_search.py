@@ -11,7 +11,7 @@ from time import time
 
 import numpy
 
-from ... import faiss
+from ... import faiss, ranks
 from ...paths import slices_data as _default_dir
 
 K = 1000
@@ -22,7 +22,7 @@ def self_search(vectors, k):
     """Normalises ``vectors`` in place, indexes them and searches them against themselves.
     Returns (scores, hits, seconds spent in the search call alone)."""
     faiss.normalize_L2(vectors)
-    flat = faiss.IndexFlat(vectors.shape[1], faiss.METRIC_INNER_PRODUCT)
+    flat = ranks.flat_index(vectors.shape[1], faiss.METRIC_INNER_PRODUCT)  # (multi-rank launch: replicated rows, split queries)
     flat.train(vectors)
     flat.add(vectors)
     began = time()
@@ -32,14 +32,16 @@ def self_search(vectors, k):
 
 def main(data_dir=None, k=K):
     folder = _default_dir() if data_dir is None else Path(data_dir)
-    todo = [name for name in SETS if not (folder / f"{name}_scores.npy").is_file()]
+    todo = ranks.same_everywhere([name for name in SETS if not (folder / f"{name}_scores.npy").is_file()])
     for name in todo:
         vectors = numpy.load(folder / f"{name}.npy").astype(numpy.float32)
-        print(name, vectors.shape)
         scores, hits, seconds = self_search(vectors, k)
-        print(seconds)
-        numpy.save(folder / f"{name}_scores.npy", scores)
-        numpy.save(folder / f"{name}_hits.npy", hits)
+        if ranks.writer():
+            print(name, vectors.shape)
+            print(seconds)
+            numpy.save(folder / f"{name}_scores.npy", scores)
+            numpy.save(folder / f"{name}_hits.npy", hits)
+        ranks.barrier()
 
 
 if __name__ == "__main__":

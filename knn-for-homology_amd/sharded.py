@@ -31,6 +31,31 @@ from . import _lib
 from . import faiss as _faiss
 
 
+def launched_group():
+    """(rank, world) of the process group the entry points spread their all-vs-all searches over.
+
+    A caller that has initialised ``torch.distributed`` itself is taken at its word.  Otherwise, under
+    ``python -m torch.distributed.run`` (RANK / WORLD_SIZE / LOCAL_RANK in the environment, WORLD_SIZE > 1) this is
+    where the launch becomes one process per GPU: the rank takes GPU LOCAL_RANK (library and torch) and joins the default
+    group over RCCL (``nccl``).  KNN355_REHEARSE_ONE_GPU=1 puts every rank on GPU 0 with gloo -- a functional rehearsal
+    on a one-GPU box.  A plain ``python -m ...`` run is (0, 1): nothing is initialised."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1 or "RANK" not in os.environ:
+        return 0, 1
+    rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    rehearse = os.environ.get("KNN355_REHEARSE_ONE_GPU") == "1"
+    device = 0 if rehearse else local
+    torch.cuda.set_device(device)
+    _lib.check(_lib.lib().knn_init(device))
+    if rehearse:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+    return rank, world
+
+
 def shard_bounds(n_total: int, world: int, rank: int):
     """Contiguous row range [lo, hi) of ``rank``: ceil(n/world) rows per shard."""
     per = (n_total + world - 1) // world
@@ -114,6 +139,13 @@ class HipShardBackend:
                                                   ctypes.c_void_p(stream)))
         return D, I
 
+    def search_self(self, k: int, row0: int, nrows: int):
+        """rows [row0, row0 + nrows) of the index as queries against all of it: host (D, I), nothing uploaded"""
+        return self.index.search_self(k, row0, nrows)
+
+    def normalize_rows(self):
+        self.index.normalize_rows()
+
     def merge(self, gathered: torch.Tensor, nlists: int, nq: int, k: int, index=None):
         D = torch.empty((nq, k), dtype=torch.float32, device=gathered.device)
         I = torch.empty((nq, k), dtype=torch.int64, device=gathered.device)
@@ -157,7 +189,7 @@ class ShardedFlatIndex:
         self.row_offset = int(row_offset)
         # exercise the keys -> all-gather -> merge path even with one rank (tests)
         self.force_collective = os.environ.get("KNN355_FORCE_COLLECTIVE", "0") == "1"
-        self.backend = backend if backend is not None else HipShardBackend(d, metric)
+        self.backend = backend if backend is not None else DEFAULT_BACKEND(d, metric)
         # a list here makes every search append a (start, end) pair of timing events recorded on the lane's
         # stream around its all-gather (bench.py reports their mean)
         self.collective_events = None
@@ -231,6 +263,9 @@ class ShardedFlatIndex:
         return D.cpu().numpy(), I.cpu().numpy()
 
 
+DEFAULT_BACKEND = HipShardBackend  # (what a sharded index is built on when none is passed; the CPU tests put their double here)
+
+
 class QueryShardedFlatIndex:
     """The other way to spread an all-vs-all over the GPUs ("alternative"): the database is
     REPLICATED -- CATH (59 MB) and Pfam (819 MB) fit any one GPU many times over -- and the queries are split:
@@ -247,18 +282,29 @@ class QueryShardedFlatIndex:
         if rank is None:
             rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.rank, self.world = rank, world
-        self.backend = backend if backend is not None else HipShardBackend(d, metric)
+        self.backend = backend if backend is not None else DEFAULT_BACKEND(d, metric)
 
     @property
     def ntotal(self):
         return self.backend.ntotal
 
+    @property
+    def replica(self):
+        """this rank's copy of the database as a plain ``faiss.IndexFlat`` (``write_index``, ``reconstruct``)"""
+        return self.backend.index
+
     def reserve(self, n):
         self.backend.reserve(n)
+
+    def train(self, x):
+        """no-op, as for IndexFlat"""
 
     def add(self, x):
         """Adds rows to THIS rank's replica: every rank adds the same rows in the same order."""
         self.backend.add(x)
+
+    def reconstruct_into(self, x):
+        self.backend.index.reconstruct_into(x)
 
     def add_dev(self, x):
         self.backend.add_dev(x)
@@ -298,6 +344,46 @@ class QueryShardedFlatIndex:
         dist.all_gather_into_tensor(Ig, Ip, group=self.group)
         # (contiguous slices of ceil(nq/world) queries: rank-major concatenation is query order)
         return Dg[:nq], Ig[:nq]
+
+    def normalize_rows(self):
+        """L2-normalises the replica's rows in HBM (every rank: the same rows, the same bits)"""
+        self.backend.normalize_rows()
+
+    def search_self(self, k, gather=True):
+        """Every row of the (replicated) database against all rows: rank r answers rows ``query_bounds(ntotal)`` --
+        its slice of the queries is already in its HBM, nothing is uploaded -- and with ``gather=True`` every rank
+        returns all ntotal rows of (D, I) as host arrays (two all-gathers), else its own slice."""
+        k = int(k)
+        n = self.ntotal
+        lo, hi = self.query_bounds(n)
+        set_batch = getattr(getattr(self.backend, "index", None), "set_batch", None)
+        if set_batch:
+            set_batch(n)  # (the slice is a piece of an n-query batch: FAISS's choice of the L2 formula)
+        try:
+            if hi > lo:
+                D, I = self.backend.search_self(k, lo, hi - lo)
+            else:
+                D, I = np.empty((0, k), np.float32), np.empty((0, k), np.int64)
+        finally:
+            if set_batch:
+                set_batch(0)
+        if not gather or self.world == 1:
+            return D, I
+        per = (n + self.world - 1) // self.world
+        # gloo gathers host tensors, RCCL device tensors
+        on_gpu = dist.get_backend(self.group) == "nccl"
+        dev = getattr(self.backend, "device", torch.device("cpu")) if on_gpu else torch.device("cpu")
+        Dp = torch.zeros((per, k), dtype=torch.float32, device=dev)
+        Ip = torch.full((per, k), -1, dtype=torch.int64, device=dev)
+        Dp[: hi - lo] = torch.from_numpy(D).to(dev)
+        Ip[: hi - lo] = torch.from_numpy(I).to(dev)
+        Dg = torch.empty((self.world * per, k), dtype=torch.float32, device=dev)
+        Ig = torch.empty((self.world * per, k), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(Dg, Dp, group=self.group)
+        dist.all_gather_into_tensor(Ig, Ip, group=self.group)
+        if on_gpu:
+            torch.cuda.current_stream(dev).synchronize()
+        return Dg[:n].cpu().numpy(), Ig[:n].cpu().numpy()
 
     def search(self, x: np.ndarray, k, gather=True):
         _faiss._check_matrix(x, self.d)

@@ -58,6 +58,15 @@ class OracleShardBackend:
         D, I = self.ko.oracle().flat_search(self.rows, q.numpy(), k, self.metric)
         return torch.from_numpy(D), torch.from_numpy(I)
 
+    def search_self(self, k, row0, nrows):
+        # (the slice is a piece of a batch of ntotal queries: the L2 formula of the whole, as the product's set_batch)
+        mode = 0 if self.metric == 0 else (2 if self.ntotal < 20 else 1)
+        return self.ko.oracle().flat_search(self.rows, self.rows[row0:row0 + nrows], k, self.metric, l2_mode=mode)
+
+    def normalize_rows(self):
+        self.rows = np.ascontiguousarray(self.rows)
+        self.ko.oracle().normalize_l2(self.rows)
+
     def merge(self, gathered, nlists, nq, k):
         g = gathered.numpy().view(np.uint64)                   # [world, nq, k]
         allk = np.sort(np.transpose(g, (1, 0, 2)).reshape(nq, nlists * k), axis=1)[:, :k]
@@ -108,6 +117,88 @@ def _worker_qs(rank, world, port, metric, out_dir):
     np.savez(Path(out_dir) / f"q{rank}.npz", D=D, I=I, Dl=Dl, Il=Il, D1=D1, I1=I1, bounds=np.array(idx.query_bounds(301)))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _worker_entry(rank, world, port, out_dir):
+    """the all-vs-all entry points under an initialised process group (what ranks.launched_group sees under
+    torch.distributed.run): cath.search.search / search_and_save, pfam.search.search_flat, slices_search.main"""
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from knn_for_homology_amd import sharded, ranks, faiss
+    from knn_for_homology_amd.cath import search as cath_search
+    from knn_for_homology_amd.pfam import search as pfam_search
+    from knn_for_homology_amd.pfam.slices import slices_search
+    from test_sharded_cpu import OracleShardBackend
+    sharded.DEFAULT_BACKEND = OracleShardBackend
+    faiss.normalize_L2 = lambda x: __import__("oracle.knn_oracle", fromlist=["oracle"]).oracle().normalize_l2(x)  # (no GPU here)
+    assert ranks.launched_group() == (rank, world) and ranks.writer() == (rank == 0)
+    out = Path(out_dir)
+    x = np.load(out / "cath" / "a.npy").astype(np.float32)
+    keep = x.copy()
+    res = {}
+    for metric in (0, 1):
+        hits, scores = cath_search.search(x, hits=7, metric=metric)
+        res[f"h{metric}"], res[f"s{metric}"] = hits, scores
+    assert np.array_equal(x, keep), "cath.search.search must not touch its input"
+    np.savez(out / f"e{rank}.npz", **res)
+    cath_search.search_and_save(out / "cath")
+    pfam_search.search_flat(out / "pfam", k=9)
+    slices_search.main(out / "slices", k=6)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_entry_points_spread_over_three_ranks(tmp_path):
+    """ranks.py: under a process group the all-vs-all entry points answer a slice of the queries per rank, every rank
+    returns the whole result, rank 0 alone writes the files -- and the files hold what one process writes."""
+    from oracle import knn_oracle as ko
+    orc = ko.oracle()
+    rng = np.random.default_rng(79)
+    for sub in ("cath", "pfam", "slices"):
+        (tmp_path / sub).mkdir()
+    a = rng.standard_normal((203, 24)).astype(np.float16)
+    b = rng.standard_normal((61, 40), dtype=np.float32)
+    np.save(tmp_path / "cath" / "a.npy", a)
+    np.save(tmp_path / "cath" / "b.npy", b)
+    train, test = rng.standard_normal((150, 16), dtype=np.float32), rng.standard_normal((37, 16), dtype=np.float32)
+    np.save(tmp_path / "pfam" / "train.npy", train)
+    np.save(tmp_path / "pfam" / "test.npy", test)
+    sl = rng.standard_normal((88, 12), dtype=np.float32)
+    np.save(tmp_path / "slices" / "slices.npy", sl)
+    np.save(tmp_path / "slices" / "full_sequences.npy", sl[:50])
+    mp.spawn(_worker_entry, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+
+    def self_search(x, k, metric):
+        x = np.ascontiguousarray(x, dtype=np.float32).copy()
+        if metric == 0:
+            orc.normalize_l2(x)
+        return orc.flat_search(x, x, k, metric)
+
+    for metric in (0, 1):
+        D, I = self_search(a, 8, metric)
+        for r in range(3):
+            got = np.load(tmp_path / f"e{r}.npz")
+            assert np.array_equal(got[f"h{metric}"], I[:, 1:]) and np.array_equal(got[f"s{metric}"].view(np.uint32), D[:, 1:].view(np.uint32))
+    for label, metric in (("cosine", 0), ("euclidean", 1)):
+        hits, scores = np.load(tmp_path / "cath" / f"hits_{label}.npz"), np.load(tmp_path / "cath" / f"scores_{label}.npz")
+        assert sorted(hits.files) == ["a", "b"]
+        for stem, x in (("a", a), ("b", b)):
+            D, I = self_search(x, 11, metric)
+            assert np.array_equal(hits[stem], I[:, 1:]) and np.array_equal(scores[stem].view(np.uint32), D[:, 1:].view(np.uint32))
+            assert float((tmp_path / "cath" / f"{stem}.{label}-search-time.txt").read_text()) >= 0.0
+    tr, te = train.copy(), test.copy()
+    orc.normalize_l2(tr)
+    orc.normalize_l2(te)
+    D, I = orc.flat_search(tr, te, 9, 0)
+    assert np.array_equal(np.load(tmp_path / "pfam" / "flat_hits.npy"), I)
+    assert np.array_equal(np.load(tmp_path / "pfam" / "flat_scores.npy").view(np.uint32), D.view(np.uint32))
+    for name, x in (("slices", sl), ("full_sequences", sl[:50])):
+        D, I = self_search(x, 6, 0)
+        assert np.array_equal(np.load(tmp_path / "slices" / f"{name}_hits.npy"), I)
+        assert np.array_equal(np.load(tmp_path / "slices" / f"{name}_scores.npy").view(np.uint32), D.view(np.uint32))
 
 
 def _free_port():
