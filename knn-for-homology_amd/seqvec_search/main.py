@@ -21,7 +21,7 @@ from typing import Iterable, List, Tuple, Union
 import numpy
 from numpy import ndarray
 
-from .. import faiss
+from .. import faiss, ranks
 from .constants import default_hits
 from .data import LoadedData
 
@@ -38,7 +38,7 @@ def faiss_search(haystack: Union[ndarray, "faiss.Index"], queries: ndarray, hits
     if isinstance(haystack, ndarray):
         if cosine:
             faiss.normalize_L2(haystack)
-        index = faiss.IndexFlat(haystack.shape[1], metric)
+        index = ranks.flat_index(haystack.shape[1], metric)  # (one GPU: faiss.IndexFlat; multi-rank launch: the queries are split, ranks.py)
         index.train(haystack)
         index.add(haystack)
     else:

@@ -143,6 +143,10 @@ def _worker_entry(rank, world, port, out_dir):
         hits, scores = cath_search.search(x, hits=7, metric=metric)
         res[f"h{metric}"], res[f"s{metric}"] = hits, scores
     assert np.array_equal(x, keep), "cath.search.search must not touch its input"
+    from knn_for_homology_amd.seqvec_search.main import faiss_search
+    tr, te = np.load(out / "pfam" / "train.npy"), np.load(out / "pfam" / "test.npy")
+    res["fs_ids"], res["fs_scores"], _ = faiss_search(tr, te, 13)   # (normalises both in place, like the reference)
+    res["fs_train"], res["fs_test"] = tr, te
     np.savez(out / f"e{rank}.npz", **res)
     cath_search.search_and_save(out / "cath")
     pfam_search.search_flat(out / "pfam", k=9)
@@ -192,6 +196,11 @@ def test_entry_points_spread_over_three_ranks(tmp_path):
     tr, te = train.copy(), test.copy()
     orc.normalize_l2(tr)
     orc.normalize_l2(te)
+    D, I = orc.flat_search(tr, te, 13, 0)
+    for r in range(3):
+        got = np.load(tmp_path / f"e{r}.npz")
+        assert np.array_equal(got["fs_ids"], I) and np.array_equal(got["fs_scores"].view(np.uint32), D.view(np.uint32))
+        assert np.array_equal(got["fs_train"], tr) and np.array_equal(got["fs_test"], te), "in-place normalisation of both arrays"
     D, I = orc.flat_search(tr, te, 9, 0)
     assert np.array_equal(np.load(tmp_path / "pfam" / "flat_hits.npy"), I)
     assert np.array_equal(np.load(tmp_path / "pfam" / "flat_scores.npy").view(np.uint32), D.view(np.uint32))
