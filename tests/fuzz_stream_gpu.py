@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer fuzz of the STREAMING regime (few queries, >= 524 k rows: paired workgroups, shared pool of tiles,
-tile-minimum seed) against the CPU oracle, bit for bit.  Random shapes / metrics / k / tuning flags (2 = no pool, 4 = no
+tile-minimum seed, batches searched in pieces) against the CPU oracle, bit for bit.  Random shapes / metrics / k / tuning flags (2 = no pool, 4 = no
 pairs, 2048 = sample pass instead of the tile-minimum seed, 8 = no seeding at all, bits 12-13 = publication rounds) and
 data kinds (gaussian, massive ties, duplicated rows, sorted so that every tile beats the previous one, constant rows,
 the best rows packed into one tile).  usage: fuzz_stream_gpu.py [ncases] [seed]"""
@@ -28,6 +28,11 @@ for case in range(ncases):
     k = int(rng.choice([1, 2, 10, 64, 100, 101, 200, 256, 481, 600, 1000, 1536]))
     metric = int(rng.integers(0, 2))
     flags = int(rng.choice([0, 0, 0, 2, 4, 2048, 2048 | 4, 8, 1 << 12, 2 << 12]))
+    if rng.integers(0, 5) == 0:  # a batch searched in pieces (the remainder behind the full 128-query tiles on its own)
+        nq = int(rng.choice([65, 96, 129, 150, 161, 193, 257]))
+        k = min(k, 256)
+        d = min(d, 32)
+        flags = int(rng.choice([0, 0, 16384, 2048]))
     kind = int(rng.integers(0, 6))
     if kind == 0:
         xb = rng.standard_normal((nb, d), dtype=np.float32)
