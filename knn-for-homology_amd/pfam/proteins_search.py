@@ -59,7 +59,7 @@ def build_index(index_mode: str, d: int):
 def run(embeddings: numpy.ndarray, index_mode: str, data_dir: Path, npy_size: int, k: int = K):
     """pfam/proteins_search.py:21-57 on an array already loaded and cast: normalises ``embeddings`` IN PLACE
     (:22 ``faiss.normalize_L2(embeddings)``), builds / writes the index, searches, saves."""
-    if index_mode != "flat" and ranks.launched_group()[1] > 1:
+    if index_mode != "flat" and ranks.launched_group()[1] > 1:  # (also: this rank's GPU is chosen before the first device call)
         # HNSW and LSH do not shard (SURVEY.md 8(e): replicas only): under a multi-rank launch rank 0 runs them on its
         # GPU, the other ranks wait for its files
         result = None

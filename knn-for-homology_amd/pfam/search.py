@@ -19,6 +19,7 @@ LSH_BITS = 1024
 
 
 def _normalised(npy: Path):
+    ranks.launched_group()  # (multi-rank launch: this rank's GPU is chosen before the first device call)
     vectors = numpy.load(npy).astype(numpy.float32)
     faiss.normalize_L2(vectors)
     return vectors

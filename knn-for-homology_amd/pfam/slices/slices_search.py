@@ -21,6 +21,7 @@ SETS = ("slices", "full_sequences")
 def self_search(vectors, k):
     """Normalises ``vectors`` in place, indexes them and searches them against themselves.
     Returns (scores, hits, seconds spent in the search call alone)."""
+    ranks.launched_group()  # (multi-rank launch: this rank's GPU is chosen before the first device call)
     faiss.normalize_L2(vectors)
     flat = ranks.flat_index(vectors.shape[1], faiss.METRIC_INNER_PRODUCT)  # (multi-rank launch: replicated rows, split queries)
     flat.train(vectors)

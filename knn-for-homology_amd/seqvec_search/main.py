@@ -32,6 +32,7 @@ def faiss_search(haystack: Union[ndarray, "faiss.Index"], queries: ndarray, hits
                  metric=faiss.METRIC_INNER_PRODUCT) -> Tuple[ndarray, ndarray, float]:
     """Searches the haystack for queries and returns the specified number of hits for each."""
     t0 = time.time()
+    ranks.launched_group()  # (multi-rank launch: this rank's GPU is chosen before the first device call)
     cosine = metric == faiss.METRIC_INNER_PRODUCT
     if cosine:
         faiss.normalize_L2(queries)
