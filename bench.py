@@ -20,7 +20,8 @@ KNN355_REHEARSE_ONE_GPU=1 puts every rank on GPU 0 with gloo as the collective b
 a functional rehearsal of the N-rank path on a one-GPU box, not a measurement.
 
 Also on the same JSON line (N=1 only, outside the timed region):
-  roofline      the scan kernel against the HBM roofline (each step reads the shard once)
+  roofline      the scan kernel against the HBM roofline (each step reads the shard once); box_read_rate: a plain read
+                kernel over the same rows on this box, for scale
   cpu_baseline  the reference's CPU path (faiss IndexFlat.search) on this box's host cores, on a
                 2 M-row sample: `value` = the fastest faithful variant -- oracle/cpu_scan.c
                 (OpenMP + AVX-512, NUMA first-touch), FAISS's blocked-sgemm algorithm on numpy's
@@ -282,6 +283,16 @@ def run(args):
             "rows_per_launch": rows_kernel, "seed_sample_rows": seed["sample_rows"],
             "mfma_tflops": 2.0 * nq * rows_kernel * d / (avg_scan_ms * 1e-3) / 1e12,
         }
+        if rank == 0 and world == 1:
+            # the same rows under a plain read kernel on THIS box (outside the timed region): boxes of a pool differ by
+            # a few percent and no kernel reaches the data-sheet 8 TB/s -- `frac` stays priced against that
+            ms_read, nbytes = ctypes.c_float(), ctypes.c_int64()
+            _lib.check(L.knn_flat_read_rate(index.local._h, 5, ctypes.byref(ms_read), ctypes.byref(nbytes)))
+            if ms_read.value > 0:
+                read_gbs = nbytes.value / (ms_read.value * 1e-3) / 1e9
+                out["roofline"]["box_read_rate"] = {
+                    "GBs": read_gbs, "ms": ms_read.value, "bytes": nbytes.value, "frac_of_it": achieved / read_gbs,
+                    "what": "knn_flat_read_rate: grid-stride 16-byte loads over the index's own rows, best of 15 launches"}
 
     if allvsall is not None:
         out["all_vs_all_query_sharded"] = allvsall

@@ -318,6 +318,12 @@ int knn_set_tuning(knn_handle h, int32_t query_tile, int32_t nchunks, int32_t fl
  * with knn_flat_view have their own). */
 int knn_flat_set_batch(knn_handle h, int64_t nq_whole);
 
+/* Measurement aid (bench.py's roofline): what THIS box's HBM delivers to a plain read kernel over the index's own rows
+ * -- grid-stride 16-byte loads, nothing else, the best of `reps` launches at three grid sizes.  best_ms = its duration,
+ * bytes_read = ntotal x padded row bytes.  A flat scan cannot be faster than this; boxes of one pool differ by a few
+ * percent, the 8 TB/s of the data sheet is not reached by any kernel. */
+int knn_flat_read_rate(knn_handle h, int32_t reps, float *best_ms, int64_t *bytes_read);
+
 #ifdef __cplusplus
 }
 #endif

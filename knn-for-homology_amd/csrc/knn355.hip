@@ -3681,6 +3681,50 @@ extern "C" int knn_set_tuning(knn_handle h, int32_t query_tile, int32_t nchunks,
     return 0;
 }
 
+// ---- measurement aid: the box's read rate over the index's own rows -----------------------------------------------
+__global__ __launch_bounds__(256) void read_rate_kernel(const f32x4 *__restrict__ p, size_t n4, float *__restrict__ sink)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (; i + 3 * stride < n4; i += 4 * stride) { // four independent 16-byte loads in flight per lane
+        const f32x4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
+        acc += a + b + c + d;
+    }
+    for (; i < n4; i += stride) acc += p[i];
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) *sink = acc[0]; // (keeps the loads alive)
+}
+
+extern "C" int knn_flat_read_rate(knn_handle h, int32_t reps, float *best_ms, int64_t *bytes_read)
+{
+    if (!h || !best_ms || !bytes_read) return set_err(KNN_ERR_INVALID, "read_rate: null pointer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t bytes = (size_t)h->ntotal * h->dp * 4;
+    *bytes_read = (int64_t)bytes;
+    *best_ms = 0.0f;
+    if (!bytes) return 0;
+    if (h->ws_flag.ensure(64, h->done, h->stream)) return set_err(KNN_ERR_HIP, "read_rate: out of device memory");
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    float best = FLT_MAX;
+    for (int grid : {2048, 4096, 8192})
+        for (int r = 0; r < std::max(1, reps); r++) {
+            HIP_TRY(hipEventRecord(e0, h->stream));
+            hipLaunchKernelGGL(read_rate_kernel, dim3(grid), dim3(256), 0, h->stream, (const f32x4 *)h->xb, bytes / 16, (float *)h->ws_flag.p + 8);
+            HIP_TRY(hipEventRecord(e1, h->stream));
+            HIP_TRY(hipEventSynchronize(e1));
+            float ms = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+            best = std::min(best, ms);
+        }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *best_ms = best;
+    return 0;
+}
+
 extern "C" int knn_flat_set_batch(knn_handle h, int64_t nq_whole)
 {
     if (!h) return set_err(KNN_ERR_INVALID, "null handle");

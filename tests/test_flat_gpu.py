@@ -971,3 +971,18 @@ def test_remainder_behind_the_full_query_tiles_is_searched_on_its_own(gpu_faiss,
         assert idx.last_scan()["kernel"] == ("flat_scan_q128_d128" if nq > 64 else "flat_scan_q64_d128")
         _assert_same(D, I, D1, I1)
         _assert_same(D, I, *oracle.flat_search(xb, xq, k, metric))
+
+
+def test_read_rate_aid_reads_the_index_rows(gpu_faiss):
+    """knn_flat_read_rate (bench.py's "box_read_rate"): a plain read pass over the index's own (padded) rows"""
+    import ctypes
+    from knn_for_homology_amd import _lib
+    rng = np.random.default_rng(1)
+    idx = gpu_faiss.IndexFlat(100, 0)  # (rows are padded to 128 floats)
+    idx.add(rng.standard_normal((50_000, 100), dtype=np.float32))
+    ms, nbytes = ctypes.c_float(), ctypes.c_int64()
+    _lib.check(_lib.lib().knn_flat_read_rate(idx._h, 2, ctypes.byref(ms), ctypes.byref(nbytes)))
+    assert nbytes.value == 50_000 * 128 * 4 and 0.0 < ms.value < 100.0
+    empty = gpu_faiss.IndexFlat(100, 0)
+    _lib.check(_lib.lib().knn_flat_read_rate(empty._h, 2, ctypes.byref(ms), ctypes.byref(nbytes)))
+    assert nbytes.value == 0 and ms.value == 0.0
