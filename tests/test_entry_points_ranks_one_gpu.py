@@ -114,3 +114,41 @@ def test_entry_points_under_a_multi_rank_launch(tmp_path, oracle, world):
                 "slices/slices_scores.npy", "slices/slices_hits.npy", "slices/full_sequences_scores.npy", "slices/full_sequences_hits.npy"):
         same_npy(rel)
     assert (many / "proteins" / "full_sequences_flat.index").read_bytes() == (one / "proteins" / "full_sequences_flat.index").read_bytes()
+
+
+def test_module_launch_under_torch_distributed_run(tmp_path):
+    """the command INTEGRATION.md gives: ``python -m torch.distributed.run ... -m knn_for_homology_amd.<script>`` on an
+    unchanged script -- here two ranks on one GPU (KNN355_REHEARSE_ONE_GPU=1), files compared with a plain run"""
+    import subprocess
+    rng = np.random.default_rng(82)
+    x = rng.standard_normal((2100, 64), dtype=np.float32)
+    outs = []
+    for name, launcher in (("many", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                     "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "-m"]),
+                           ("one", [sys.executable, "-m"])):
+        root = tmp_path / name
+        (root / "pfam" / "full_sequences_data").mkdir(parents=True)
+        (root / "cath" / "data").mkdir(parents=True)
+        np.save(root / "pfam" / "full_sequences_data" / "full_sequences.npy", x)
+        np.save(root / "cath" / "data" / "emb.npy", x[:900].astype(np.float16))
+        env = dict(os.environ, KNN355_PROJECT_ROOT=str(root), KNN355_REHEARSE_ONE_GPU="1",
+                   PYTHONPATH=str(ROOT) + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        for var in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(var, None)
+        for module, extra in (("knn_for_homology_amd.pfam.proteins_search", ["flat"]), ("knn_for_homology_amd.cath.search", [])):
+            r = subprocess.run(launcher + [module] + extra, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+            outs.append((name, module, r.stdout))
+    # rank 0 alone printed: the protocol lines appear once
+    for name, module, stdout in outs:
+        if module.endswith("proteins_search"):
+            assert stdout.count("Index creation took") == 1 and stdout.count("Search took") == 1, (name, stdout)
+        else:
+            assert stdout.count("Searching with Cosine") == 1, (name, stdout)
+    for rel in ("pfam/full_sequences_data/full_sequences_flat_scores.npy", "pfam/full_sequences_data/full_sequences_flat_hits.npy",
+                "pfam/full_sequences_data/full_sequences_flat.index"):
+        assert (tmp_path / "many" / rel).read_bytes() == (tmp_path / "one" / rel).read_bytes(), rel
+    for label in ("cosine", "euclidean"):
+        a = np.load(tmp_path / "many" / "cath" / "data" / f"hits_{label}.npz")
+        b = np.load(tmp_path / "one" / "cath" / "data" / f"hits_{label}.npz")
+        assert np.array_equal(a["emb"], b["emb"])
