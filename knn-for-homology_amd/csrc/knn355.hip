@@ -485,6 +485,140 @@ __device__ __forceinline__ int wave_filter_dispatch(int R, uint64_t *lst, int n,
     return wave_filter<32>(lst, n, T, lane);
 }
 
+// The same selection for arrays too long for one wave's registers (up to 4096 keys: lists of a search with k in
+// (1536, 2048], 4096 published keys): nothing is cached, every probe re-reads the array (64-bit loads, coalesced, L2
+// hits; eight in flight per lane).  A handful of probes of <= 64 loads per lane against a workgroup-wide LDS sort of
+// 4096 keys (78 barrier-separated stages) that kept all four waves on one query.  Same contract as wave_select:
+// keeps k .. kmax keys (the k best among them), packed to the front of dst, unsorted; dst may be the array itself --
+// the packing of iteration r writes below index 64 (r + 1), all of which has been read by then.
+template <typename LD>
+__device__ __attribute__((noinline)) int wave_select_mem(LD load, int n, int k, int kmax, int lane, uint32_t *thr_ord, uint64_t *dst)
+{
+    n = __builtin_amdgcn_readfirstlane(n);
+    k = __builtin_amdgcn_readfirstlane(k);
+    kmax = __builtin_amdgcn_readfirstlane(kmax);
+    const int iters = (n + 63) >> 6;
+    // fn(key, valid) for every key of this lane, eight loads in flight
+    auto for_each = [&](auto &&fn) {
+        int r = 0;
+        for (; r + 8 <= iters; r += 8) {
+            uint64_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int idx = (r + u) * 64 + lane;
+                v[u] = load(idx < n ? idx : n - 1);
+                if (idx >= n) v[u] = KEY_PAD;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) fn(v[u]);
+        }
+        for (; r < iters; r++) {
+            const int idx = r * 64 + lane;
+            uint64_t v = load(idx < n ? idx : n - 1);
+            if (idx >= n) v = KEY_PAD;
+            fn(v);
+        }
+    };
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+    int real = 0;
+    for_each([&](uint64_t key) {
+        const uint32_t hi = (uint32_t)(key >> 32);
+        mn = min(mn, hi);
+        if (hi != 0xFFFFFFFFu) {
+            mx = max(mx, hi);
+            real++;
+        }
+    });
+    mn = wave_min_u32(mn);
+    mx = wave_max_u32(mx);
+    real = wave_sum(real); // keys whose score word is not the padding word
+    auto count_lt = [&](uint32_t X) {
+        int c = 0;
+        for_each([&](uint64_t key) { c += (uint32_t)(key >> 32) < X ? 1 : 0; });
+        return wave_sum(c);
+    };
+    uint32_t T = 0xFFFFFFFFu; // keep every key with score word <= T (0xFFFFFFFF: every real key)
+    int cnt = real;
+    if (real > kmax && mn != mx) {
+        uint32_t lo_x = mn, hi_x = mx + 1u;
+        int f_lo = 0, f_hi = real;
+        const float target = 0.5f * (float)(k + kmax);
+        bool interpolate = true, done = false;
+        while (hi_x - lo_x > 1u) {
+            uint32_t X;
+            if (interpolate)
+                X = lo_x + (uint32_t)((float)(hi_x - lo_x) * ((target - (float)f_lo) / (float)(f_hi - f_lo)));
+            else
+                X = lo_x + ((hi_x - lo_x) >> 1);
+            X = max(lo_x + 1u, min(X, hi_x - 1u));
+            interpolate = !interpolate;
+            const int c = count_lt(X);
+            if (c < k) {
+                lo_x = X;
+                f_lo = c;
+            } else if (c > kmax) {
+                hi_x = X;
+                f_hi = c;
+            } else {
+                T = X - 1u;
+                cnt = c;
+                done = true;
+                break;
+            }
+        }
+        if (!done) { // lo_x is the exact k-th smallest score word
+            T = lo_x;
+            cnt = f_hi;
+        }
+    } else if (real > kmax) {
+        T = mn; // every real key carries the same score word: the id tie-break below decides
+    }
+    uint32_t Q = 0xFFFFFFFFu;
+    if (cnt > kmax && T != 0xFFFFFFFFu) {
+        // more keys tie at T than may be kept: lowest ids win
+        const int need = k - count_lt(T);
+        Q = 0u;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t Qt = Q | (1u << bit);
+            int c = 0;
+            for_each([&](uint64_t key) { c += ((uint32_t)(key >> 32) == T && (uint32_t)key < Qt) ? 1 : 0; });
+            if (wave_sum(c) <= need - 1) Q = Qt;
+        }
+    }
+    // survivors, 64 keys per step, packed in place with a ballot (see above for why dst may alias the array)
+    int base = 0;
+    for (int r = 0; r < iters; r++) {
+        const int idx = r * 64 + lane;
+        uint64_t key = load(idx < n ? idx : n - 1);
+        if (idx >= n) key = KEY_PAD;
+        const uint32_t hi = (uint32_t)(key >> 32);
+        const bool keep = hi != 0xFFFFFFFFu && (hi < T || (hi == T && (uint32_t)key <= Q));
+        const unsigned long long m = __ballot(keep);
+        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (keep && pos < kmax && dst) dst[pos] = key;
+        base += __popcll(m);
+    }
+    *thr_ord = T;
+    return min(base, kmax);
+}
+
+// ... and the threshold filter for such an array: keeps the keys with score word <= T, packed in place
+__device__ __attribute__((noinline)) int wave_filter_mem(uint64_t *lst, int n, uint32_t T, int lane)
+{
+    n = __builtin_amdgcn_readfirstlane(n);
+    T = __builtin_amdgcn_readfirstlane(T);
+    int base = 0;
+    for (int r = 0; r < (n + 63) >> 6; r++) {
+        const int idx = r * 64 + lane;
+        const uint64_t key = idx < n ? ((gptr_u64)lst)[idx] : KEY_PAD;
+        const bool keep = key != KEY_PAD && (uint32_t)(key >> 32) <= T;
+        const unsigned long long m = __ballot(keep);
+        if (keep) lst[base + __popcll(m & ((1ull << lane) - 1ull))] = key;
+        base += __popcll(m);
+    }
+    return base;
+}
+
 // ---------------------------------------------------------------------------
 // scan kernel
 // ---------------------------------------------------------------------------
@@ -607,8 +741,13 @@ __device__ __forceinline__ void lists_compact(ListCtx &L, char *smem, int tile_r
 {
     const int lane = tid & 63, wave = tid >> 6;
     const int R = L.cap >> 6;
-    if (R <= 32) {
-        // one wave per query, registers only: one query in flight per wave of the workgroup
+    if (R <= 64) {
+        // one wave per query: one query in flight per wave of the workgroup.  Lists of up to 2048 keys are selected in
+        // registers, the 4096-key lists of k in (1536, 2048] by probing the list in memory (wave_select_mem)
+        auto select = [&](uint64_t *lst, int n, int kmax, uint32_t *T) -> int {
+            if (R <= 32) return wave_select_dispatch(R, LoadContig{lst}, n, L.k, kmax, lane, T, lst);
+            return wave_select_mem(LoadContig{lst}, n, L.k, kmax, lane, T, lst);
+        };
         for (int ql = wave; ql < QT; ql += NT / 64) {
             const int n = __builtin_amdgcn_readfirstlane(min(L.s_cnt[ql], L.cap));
             uint64_t *lst = L.lists + (size_t)ql * L.cap;
@@ -626,12 +765,13 @@ __device__ __forceinline__ void lists_compact(ListCtx &L, char *smem, int tile_r
                 }
                 kmax = L.kslot;
                 if (L.prefilter) {
-                    const int m = wave_filter_dispatch(R, lst, n, f2ord(L.threshold(ql)), lane);
+                    const int m = R <= 32 ? wave_filter_dispatch(R, lst, n, f2ord(L.threshold(ql)), lane)
+                                          : wave_filter_mem(lst, n, f2ord(L.threshold(ql)), lane);
                     if (m <= L.kslot) {
                         if (lane == 0) L.s_cnt[ql] = m;
                         continue;
                     }
-                    const int cnt2 = wave_select_dispatch(R, LoadContig{lst}, m, L.k, kmax, lane, &T, lst);
+                    const int cnt2 = select(lst, m, kmax, &T);
                     if (lane == 0) {
                         L.s_cnt[ql] = cnt2;
                         L.s_thr[ql] = ord2f(T);
@@ -640,7 +780,7 @@ __device__ __forceinline__ void lists_compact(ListCtx &L, char *smem, int tile_r
                     continue;
                 }
             }
-            const int cnt = wave_select_dispatch(R, LoadContig{lst}, n, L.k, kmax, lane, &T, lst);
+            const int cnt = select(lst, n, kmax, &T);
             if (lane == 0) {
                 L.s_cnt[ql] = cnt;
                 L.s_thr[ql] = ord2f(T);
@@ -649,7 +789,7 @@ __device__ __forceinline__ void lists_compact(ListCtx &L, char *smem, int tile_r
         }
         __syncthreads();
     } else {
-        // k > 1536: lists too long for the register select, whole-workgroup LDS sort
+        // lists longer than 4096 keys (no plan makes them: k <= 2048): whole-workgroup LDS sort
         uint64_t *sb = (uint64_t *)smem;
         for (int ql = 0; ql < QT; ql++) {
             const int n = min(L.s_cnt[ql], L.cap);
@@ -1291,8 +1431,11 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
                     if (q0 + ql < p.nq && (a + 1) * p.pub_m >= p.k) {
                         uint32_t T = 0xFFFFFFFFu;
                         const int kmax = p.k + max(p.k >> 2, 32);
-                        wave_select_dispatch((p.pub_n + 63) >> 6, LoadAgent{p.pub + (size_t)(q0 + ql) * p.pub_n}, p.pub_n, p.k, kmax, lane, &T,
-                                             (uint64_t *)nullptr);
+                        if (p.pub_n <= 2048)
+                            wave_select_dispatch((p.pub_n + 63) >> 6, LoadAgent{p.pub + (size_t)(q0 + ql) * p.pub_n}, p.pub_n, p.k, kmax, lane, &T,
+                                                 (uint64_t *)nullptr);
+                        else
+                            wave_select_mem(LoadAgent{p.pub + (size_t)(q0 + ql) * p.pub_n}, p.pub_n, p.k, kmax, lane, &T, (uint64_t *)nullptr);
                         if (lane == 0 && T != 0xFFFFFFFFu) atomicMin(&L.gthr[ql], T);
                     }
                 }
@@ -2455,7 +2598,11 @@ extern "C" int knn_flat_reconstruct(knn_handle h, int64_t i0, int64_t n, float *
 // is exact.  The register select inside the scan kernels serves k <= 1536 (lists of <= 2048
 // keys, 32 per lane, so that 1.25 k + one tile fits); beyond that the workgroup sort takes
 // exactly k.
-static const int KNN_WAVE_SELECT_MAX_K = 1536;
+static const int KNN_WAVE_SELECT_MAX_K = 2048;    // one wave selects a list: in registers up to ...
+// ... this k (2048-key lists), by probing a 4096-key list in memory beyond.  1.25 k keys + a tile of appends fit a 2048-key
+// list up to k = 1536, but the closer k gets the less room a cut leaves and the more often a list is cut: measured crossover
+// at k ~ 1400 (2 M rows x 1024 queries: k = 1400 43.4 ms either way, k = 1536 51.3 ms with 2048-key lists, 44.8 with 4096)
+static const int KNN_REGISTER_SELECT_MAX_K = 1400;
 static int knn_kslot(int k) { return k > KNN_WAVE_SELECT_MAX_K ? k : k + k / 4; }
 
 static int next_pow2_host(int n)
@@ -2589,7 +2736,12 @@ static void make_plan(const knn_index_s *h, int64_t nb, int64_t nq, int k, bool 
     pl.nqtiles = (int)((nq + qt - 1) / qt);
     pl.cap = next_pow2_host(2 * k + pl.dt);
     if (pl.cap < 512) pl.cap = 512;
-    if (k <= KNN_WAVE_SELECT_MAX_K) pl.cap = std::min(pl.cap, 2048); // register select: <= 32 keys per lane
+    int regsel_max = KNN_REGISTER_SELECT_MAX_K;
+#ifdef KNN355_DEV
+    if (getenv("KNN355_REGSEL_MAX_K")) regsel_max = atoi(getenv("KNN355_REGSEL_MAX_K")); // (developer build: where the 4096-key lists take over)
+#endif
+    if (k <= regsel_max) pl.cap = std::min(pl.cap, 2048); // register select: <= 32 keys per lane
+    else if (k <= KNN_WAVE_SELECT_MAX_K) pl.cap = std::min(pl.cap, 4096);  // wave_select_mem: 1.25 k + a tile of appends fit
     const int64_t ntiles = (nb + pl.dt - 1) / pl.dt;
     pl.npairs = 0;
     if (allow_pairs && pl.nqtiles == 1 && h->force_chunks <= 0 && !(h->flags & 4) && ntiles >= 8 * (int64_t)std::max(1, h->num_cus)) {
@@ -2766,10 +2918,12 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
         // -P ln(1 - k / P) / (P x rows per wave) quantile (k = 1000, P = 2048: 1372 of 131 k sampled rows; 2 M rows x 32
         // queries: 2.30 ms unseeded -- every workgroup warming up its own 1000 best -- against 1.45 at k = 100).
         const int wm = pl.qt == 32 ? 4 : 2;
-        const int64_t P = (int64_t)wm * pl.nchunks;
-        if (P <= 2048 && P >= (int64_t)k + k / 4 + 32 && pl.tiles_base > 1) {
-            pub_rounds = 1;
-            pub_m = wm;
+        for (int r = 2; r >= 1; r--) { // (one round if it gives enough publications; 4096 keys are selected by probing them in memory)
+            const int64_t P = (int64_t)r * wm * pl.nchunks;
+            if (P <= 4096 && P >= (int64_t)k + k / 4 + 32 && r < pl.tiles_base) {
+                pub_rounds = r;
+                pub_m = wm;
+            }
         }
     }
     if (pub_rounds) {
@@ -2778,8 +2932,8 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
         // again at the end of the chunk
         expect_n = 2.0 * (double)k * (double)nb / ((double)pub_rounds * pl.nchunks * pl.dt) + 2.0 * k + 64;
         if (pub_m > 1) {
-            const double P = (double)pub_m * pl.nchunks;
-            expect_n = 1.3 * (-P * log(1.0 - (double)k / P)) * (double)nb / ((double)pl.nchunks * pl.dt) + 2.0 * k + 64;
+            const double P = (double)pub_rounds * pub_m * pl.nchunks;
+            expect_n = 1.3 * (-P * log(1.0 - (double)k / P)) * (double)nb / ((double)pub_rounds * pl.nchunks * pl.dt) + 2.0 * k + 64;
         }
     }
     if (!sstride && !pub_rounds) make_plan(h, nb, nq, k, level > 0, pl, allow_pairs && level == 0); // a seed sample is small: parallelism over warm-up
@@ -3155,7 +3309,7 @@ extern "C" int knn_merge_keys_dev(knn_handle h, const uint64_t *keys_dev, int32_
 static bool self_search_symmetric_eligible(const knn_index_s *h, int k, int *j_out = nullptr, int *qcap_out = nullptr)
 {
     const int64_t n = h->ntotal;
-    if (n < 8192 || k > KNN_WAVE_SELECT_MAX_K || k >= n || (h->flags & (8 | 16 | 512 | 1024)) || h->force_qt || h->force_chunks || h->approx16) return false;
+    if (n < 8192 || k > KNN_REGISTER_SELECT_MAX_K || k >= n || (h->flags & (8 | 16 | 512 | 1024)) || h->force_qt || h->force_chunks || h->approx16) return false;
     int st = n >= (1 << 20) ? 64 : 32;
 #ifdef KNN355_DEV
     if (getenv("KNN355_STAT_STRIDE")) st = atoi(getenv("KNN355_STAT_STRIDE"));

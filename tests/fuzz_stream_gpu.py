@@ -25,7 +25,7 @@ for case in range(ncases):
     d = int(rng.choice([8, 16, 31, 32, 48, 64]))
     nb = int(rng.choice([524_288, 530_000, 600_001, 777_777, 1_048_577, 1_300_000]))
     nq = int(rng.choice([1, 2, 7, 31, 32, 33, 64]))
-    k = int(rng.choice([1, 2, 10, 64, 100, 101, 200, 256, 481, 600, 1000, 1536]))
+    k = int(rng.choice([1, 2, 10, 64, 100, 101, 200, 256, 481, 600, 1000, 1536, 1537, 1800, 2048]))
     metric = int(rng.integers(0, 2))
     flags = int(rng.choice([0, 0, 0, 2, 4, 2048, 2048 | 4, 8, 1 << 12, 2 << 12]))
     if rng.integers(0, 5) == 0:  # a batch searched in pieces (the remainder behind the full 128-query tiles on its own)

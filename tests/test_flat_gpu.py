@@ -797,6 +797,32 @@ def test_tile_minimum_seed_with_one_key_per_wave_for_large_k(gpu_faiss, oracle, 
     _assert_same(D2, I2, Do, Io)
 
 
+@pytest.mark.parametrize("metric,nb,d,nq,k,seed", [(0, 620_000, 32, 32, 1537, -4), (1, 620_000, 24, 9, 2048, -8), (0, 560_000, 32, 32, 1800, -8),
+                                                   (1, 620_000, 32, 50, 2048, None), (0, 30_000, 48, 300, 2048, None), (1, 9_000, 64, 130, 1700, None),
+                                                   (0, 4_100, 32, 5, 2048, None), (1, 2_049, 40, 33, 2048, None)])
+def test_k_between_1537_and_2048_selects_by_probing_the_list(gpu_faiss, oracle, metric, nb, d, nq, k, seed):
+    """k in (1536, 2048]: the 4096-key candidate lists are cut by one wave that probes them in memory (wave_select_mem)
+    instead of a workgroup-wide sort, and a streaming launch seeds itself from 2048 or 4096 published keys.  Streaming,
+    batch and small-database shapes, duplicates and ties: the oracle's bits, with and without seeding."""
+    rng = np.random.default_rng(nb + k + nq)
+    xb = rng.standard_normal((nb, d), dtype=np.float32)
+    dup = min(900, nb // 4)
+    xb[nb // 2: nb // 2 + dup] = xb[:dup]
+    xb[-40:] = 0.0
+    xq = np.concatenate([rng.standard_normal((max(nq - 2, 0), d), dtype=np.float32), xb[:min(2, nq)]])[:nq]
+    idx = gpu_faiss.IndexFlat(d, metric)
+    idx.add(xb)
+    D, I = idx.search(xq, k)
+    if seed is not None:
+        assert idx.last_seed()["stride"] == seed, (idx.last_seed(), idx.last_scan())
+    Do, Io = oracle.flat_search(xb, xq, k, metric)
+    _assert_same(D, I, Do, Io)
+    for flags in (8, 2048, 4):
+        idx.set_tuning(0, 0, flags)
+        D2, I2 = idx.search(xq, k)
+        _assert_same(D2, I2, Do, Io)
+
+
 def test_per_wave_publications_with_adversarial_order(gpu_faiss, oracle):
     """every chunk's first tile holds its worst rows, the best rows of the database sit at its end: a loose bound, never a
     wrong one (k = 1000, four keys per workgroup)"""
