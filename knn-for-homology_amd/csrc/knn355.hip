@@ -619,6 +619,15 @@ __device__ __attribute__((noinline)) int wave_filter_mem(uint64_t *lst, int n, u
     return base;
 }
 
+// The bound of a tile-minimum seed: the k-th smallest of the keys published so far (one call site in the scan kernel:
+// a second one -- the memory-probing variant next to the register variant -- cost a 1.25 M-row launch 70 us)
+__device__ __attribute__((noinline)) void published_bound(const uint64_t *pub, int n, int k, int kmax, int lane, uint32_t *thr_ord)
+{
+    n = __builtin_amdgcn_readfirstlane(n);
+    if (n <= 2048) wave_select_dispatch((n + 63) >> 6, LoadAgent{pub}, n, k, kmax, lane, thr_ord, (uint64_t *)nullptr);
+    else wave_select_mem(LoadAgent{pub}, n, k, kmax, lane, thr_ord, (uint64_t *)nullptr);
+}
+
 // ---------------------------------------------------------------------------
 // scan kernel
 // ---------------------------------------------------------------------------
@@ -1431,11 +1440,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
                     if (q0 + ql < p.nq && (a + 1) * p.pub_m >= p.k) {
                         uint32_t T = 0xFFFFFFFFu;
                         const int kmax = p.k + max(p.k >> 2, 32);
-                        if (p.pub_n <= 2048)
-                            wave_select_dispatch((p.pub_n + 63) >> 6, LoadAgent{p.pub + (size_t)(q0 + ql) * p.pub_n}, p.pub_n, p.k, kmax, lane, &T,
-                                                 (uint64_t *)nullptr);
-                        else
-                            wave_select_mem(LoadAgent{p.pub + (size_t)(q0 + ql) * p.pub_n}, p.pub_n, p.k, kmax, lane, &T, (uint64_t *)nullptr);
+                        published_bound(p.pub + (size_t)(q0 + ql) * p.pub_n, p.pub_n, p.k, kmax, lane, &T);
                         if (lane == 0 && T != 0xFFFFFFFFu) atomicMin(&L.gthr[ql], T);
                     }
                 }
