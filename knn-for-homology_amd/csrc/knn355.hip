@@ -2608,6 +2608,15 @@ static const int KNN_WAVE_SELECT_MAX_K = 2048;    // one wave selects a list: in
 // list up to k = 1536, but the closer k gets the less room a cut leaves and the more often a list is cut: measured crossover
 // at k ~ 1400 (2 M rows x 1024 queries: k = 1400 43.4 ms either way, k = 1536 51.3 ms with 2048-key lists, 44.8 with 4096)
 static const int KNN_REGISTER_SELECT_MAX_K = 1400;
+// (developer build: integer knobs from the environment; the shipped library has the defaults compiled in)
+static int dev_knob(const char *name, int dflt)
+{
+#ifdef KNN355_DEV
+    if (getenv(name)) return atoi(getenv(name));
+#endif
+    (void)name;
+    return dflt;
+}
 static int knn_kslot(int k) { return k > KNN_WAVE_SELECT_MAX_K ? k : k + k / 4; }
 
 static int next_pow2_host(int n)
@@ -2749,7 +2758,7 @@ static void make_plan(const knn_index_s *h, int64_t nb, int64_t nq, int k, bool 
     else if (k <= KNN_WAVE_SELECT_MAX_K) pl.cap = std::min(pl.cap, 4096);  // wave_select_mem: 1.25 k + a tile of appends fit
     const int64_t ntiles = (nb + pl.dt - 1) / pl.dt;
     pl.npairs = 0;
-    if (allow_pairs && pl.nqtiles == 1 && h->force_chunks <= 0 && !(h->flags & 4) && ntiles >= 8 * (int64_t)std::max(1, h->num_cus)) {
+    if (allow_pairs && pl.nqtiles == 1 && h->force_chunks <= 0 && !(h->flags & 4) && ntiles >= (int64_t)dev_knob("KNN355_PAIR_TILES_PER_CU", 2) * (int64_t)std::max(1, h->num_cus)) {
         // one query tile, plenty of tiles: two workgroups per CU, paired (see flat_scan_kernel): each pair shares a
         // contiguous range of ~ ntiles / CUs tiles
         pl.npairs = std::max(1, h->num_cus);
@@ -2908,7 +2917,7 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     // is the bound.  Needs: the 32- or 64-query tile, plain fp32 rows, a few times k publications that fit one wave's
     // registers (<= 2048), chunks long enough that an unfiltered first tile is noise.  flags & 2048: never.
     int pub_rounds = 0, pub_m = 1;
-    const bool pub_shape = !(h->flags & (8 | 16 | 128 | 2048)) && !h->approx16 && pl.qt <= 64 && pl.cap >= 2 * pl.dt && pl.tiles_base >= (pl.npairs ? 8 : 4);
+    const bool pub_shape = !(h->flags & (8 | 16 | 128 | 2048)) && !h->approx16 && pl.qt <= 64 && pl.cap >= 2 * pl.dt && pl.tiles_base >= (pl.npairs ? dev_knob("KNN355_PUB_MIN_TILES_PAIRED", 2) : 4);
     if (seed && pub_shape) {
         for (int r = 2; r >= 1; r--) // (one round if it gives enough publications)
             if ((int64_t)r * pl.nchunks <= 2048 && (int64_t)r * pl.nchunks >= 2 * (int64_t)k + 64 && r < pl.tiles_base) pub_rounds = r;

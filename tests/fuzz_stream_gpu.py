@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer fuzz of the STREAMING regime (few queries, >= 524 k rows: paired workgroups, shared pool of tiles,
+"""Developer fuzz of the STREAMING regime (few queries, >= 131 k rows: paired workgroups, shared pool of tiles,
 tile-minimum seed, batches searched in pieces) against the CPU oracle, bit for bit.  Random shapes / metrics / k / tuning flags (2 = no pool, 4 = no
 pairs, 2048 = sample pass instead of the tile-minimum seed, 8 = no seeding at all, bits 12-13 = publication rounds) and
 data kinds (gaussian, massive ties, duplicated rows, sorted so that every tile beats the previous one, constant rows,
@@ -23,7 +23,7 @@ fails = 0
 t0 = time.time()
 for case in range(ncases):
     d = int(rng.choice([8, 16, 31, 32, 48, 64]))
-    nb = int(rng.choice([524_288, 530_000, 600_001, 777_777, 1_048_577, 1_300_000]))
+    nb = int(rng.choice([131_072, 140_000, 200_001, 262_144, 300_000, 400_003, 524_288, 530_000, 600_001, 777_777, 1_048_577, 1_300_000]))
     nq = int(rng.choice([1, 2, 7, 31, 32, 33, 64]))
     k = int(rng.choice([1, 2, 10, 64, 100, 101, 200, 256, 481, 600, 1000, 1536, 1537, 1800, 2048]))
     metric = int(rng.integers(0, 2))

@@ -823,6 +823,32 @@ def test_k_between_1537_and_2048_selects_by_probing_the_list(gpu_faiss, oracle, 
         _assert_same(D2, I2, Do, Io)
 
 
+@pytest.mark.parametrize("metric,nb,d,nq,k", [(0, 131_072, 32, 32, 100), (1, 131_073, 32, 7, 10), (0, 140_000, 24, 32, 300), (1, 200_000, 32, 64, 100),
+                                              (0, 262_144, 32, 32, 100), (1, 300_001, 40, 19, 50), (0, 400_000, 32, 48, 600), (1, 66_000, 32, 40, 20)])
+def test_short_streaming_launches_pair_and_seed_themselves(gpu_faiss, oracle, metric, nb, d, nq, k):
+    """From two tiles per CU on (131 k rows with the 32-query tile, 66 k with the 64-query tile) a one-query-tile launch
+    pairs its workgroups and seeds itself: every pair shares 2-8 tiles, a workgroup may walk a single one (whose parked
+    scores it filters on the spot).  Shards of a 1-4 M-row database on eight GPUs are this size.  Same bits as the
+    oracle, as static chunks (flags 4), as the sample pass (2048) and unseeded (8)."""
+    rng = np.random.default_rng(nb + k)
+    xb = rng.standard_normal((nb, d), dtype=np.float32)
+    xb[nb // 2: nb // 2 + 200] = xb[:200]
+    xb[-30:] = 0.0
+    xq = np.concatenate([rng.standard_normal((max(nq - 2, 0), d), dtype=np.float32), xb[:min(2, nq)]])[:nq]
+    idx = gpu_faiss.IndexFlat(d, metric)
+    idx.add(xb)
+    D, I = idx.search(xq, k)
+    assert idx.last_seed()["stride"] < 0 and idx.last_scan()["grid"] == 512, (idx.last_seed(), idx.last_scan())
+    Do, Io = oracle.flat_search(xb, xq, k, metric)
+    _assert_same(D, I, Do, Io)
+    D1, I1 = idx.search(xq, k)
+    _assert_same(D1, I1, Do, Io)
+    for flags in (4, 2048, 8, 2):
+        idx.set_tuning(0, 0, flags)
+        D2, I2 = idx.search(xq, k)
+        _assert_same(D2, I2, Do, Io)
+
+
 def test_per_wave_publications_with_adversarial_order(gpu_faiss, oracle):
     """every chunk's first tile holds its worst rows, the best rows of the database sit at its end: a loose bound, never a
     wrong one (k = 1000, four keys per workgroup)"""
