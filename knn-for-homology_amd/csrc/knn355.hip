@@ -2758,10 +2758,10 @@ static void make_plan(const knn_index_s *h, int64_t nb, int64_t nq, int k, bool 
     else if (k <= KNN_WAVE_SELECT_MAX_K) pl.cap = std::min(pl.cap, 4096);  // wave_select_mem: 1.25 k + a tile of appends fit
     const int64_t ntiles = (nb + pl.dt - 1) / pl.dt;
     pl.npairs = 0;
-    if (allow_pairs && pl.nqtiles == 1 && h->force_chunks <= 0 && !(h->flags & 4) && ntiles >= (int64_t)dev_knob("KNN355_PAIR_TILES_PER_CU", 2) * (int64_t)std::max(1, h->num_cus)) {
+    if (allow_pairs && pl.nqtiles == 1 && h->force_chunks <= 0 && !(h->flags & 4) && ntiles >= (int64_t)dev_knob("KNN355_PAIR_MIN_TILES", 64)) {
         // one query tile, plenty of tiles: two workgroups per CU, paired (see flat_scan_kernel): each pair shares a
-        // contiguous range of ~ ntiles / CUs tiles
-        pl.npairs = std::max(1, h->num_cus);
+        // contiguous range of ~ ntiles / CUs tiles (at least two: fewer pairs than CUs on a small database)
+        pl.npairs = (int)std::min<int64_t>(std::max(1, h->num_cus), ntiles / 2);
         pl.nchunks = 2 * pl.npairs;
         pl.grid = pl.nchunks;
         pl.tiles_base = (int)(ntiles / pl.npairs);
@@ -2914,8 +2914,10 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     }
     // Tile-minimum seed (see flat_scan_kernel): where the exact seed would run a sample pass first, a launch with enough
     // chunks seeds itself -- each chunk publishes its first tiles' best key per query, the k-th smallest published key
-    // is the bound.  Needs: the 32- or 64-query tile, plain fp32 rows, a few times k publications that fit one wave's
-    // registers (<= 2048), chunks long enough that an unfiltered first tile is noise.  flags & 2048: never.
+    // is the bound.  Needs: the 32- or 64-query tile, plain fp32 rows, enough publications for k (<= 4096 of them).
+    // flags & 2048: never.  (The 128-query tile of a one-query-tile launch was tried: 100 k rows x 128 queries 0.66 -> 0.38 ms
+    // where no sample pass exists, but the code in that build cost its other launches 2-14 % -- 1.25 M rows 2.80 -> 3.20 ms;
+    // such batches are searched as two 64-query pieces instead, see search_keys_impl.)
     int pub_rounds = 0, pub_m = 1;
     const bool pub_shape = !(h->flags & (8 | 16 | 128 | 2048)) && !h->approx16 && pl.qt <= 64 && pl.cap >= 2 * pl.dt && pl.tiles_base >= (pl.npairs ? dev_knob("KNN355_PUB_MIN_TILES_PAIRED", 2) : 4);
     if (seed && pub_shape) {
@@ -3163,8 +3165,17 @@ static int search_keys_impl(knn_index_s *h, const float *q_dev, int64_t nq, int 
     };
     std::vector<Piece> pieces;
     const bool split = h->ntotal >= (1 << 18) && !h->force_qt && !(h->flags & 16384);
+    // A database of 32 k .. 262 k rows has no sample pass to seed a 128-query launch with, and the 64-query build seeds
+    // itself: a batch of 65..128 queries goes as two 64-query pieces (100 k rows x 100 queries: 0.56 -> 0.41 ms).
+    const bool split_small = !split && h->ntotal >= (1 << 15) && nq > 64 && nq <= 128 && !h->force_qt && !h->force_chunks && !h->approx16 &&
+                             !(h->flags & (8 | 16 | 128 | 2048 | 16384));
     for (int64_t b = 0; b < nblocks; b++) {
         const int64_t q0 = b * QB, m = nblocks == 1 ? nq : std::min(QB, nq - q0);
+        if (split_small) {
+            pieces.push_back({q0, 64});
+            pieces.push_back({q0 + 64, m - 64});
+            continue;
+        }
         const int64_t full = m / 128 * 128, r = m - full;
         if (!split || m <= 64 || r == 0 || r > 96 || (r > 64 && full)) { // (65..96 behind full tiles: the two narrow passes cost what the padded tile does)
             pieces.push_back({q0, m});

@@ -849,6 +849,29 @@ def test_short_streaming_launches_pair_and_seed_themselves(gpu_faiss, oracle, me
         _assert_same(D2, I2, Do, Io)
 
 
+@pytest.mark.parametrize("metric", [0, 1])
+def test_batches_of_65_to_128_queries_on_a_mid_sized_database_go_as_two_pieces(gpu_faiss, oracle, metric):
+    """32 k .. 262 k rows: no sample pass exists to seed a 128-query launch with, the 64-query build seeds itself -- the
+    batch is searched as two 64-query pieces.  Same bits as the one 128-query launch (flags 16384) and as the oracle."""
+    rng = np.random.default_rng(65 + metric)
+    nb, d, k = 100_000, 32, 40
+    xb = rng.standard_normal((nb, d), dtype=np.float32)
+    xb[700:760] = xb[:60]
+    idx = gpu_faiss.IndexFlat(d, metric)
+    idx.add(xb)
+    for nq in (65, 100, 128, 64, 129):
+        xq = rng.standard_normal((nq, d), dtype=np.float32)
+        xq[0] = xb[3]
+        idx.set_tuning(0, 0, 0)
+        D, I = idx.search(xq, k)
+        assert idx.last_scan()["kernel"] == ("flat_scan_q128_d128" if nq > 128 else ("flat_scan_q64_d128" if nq != 65 else "flat_scan_q32_d256")), (nq, idx.last_scan())
+        idx.set_tuning(0, 0, 16384)
+        D1, I1 = idx.search(xq, k)
+        assert idx.last_scan()["kernel"] == ("flat_scan_q128_d128" if nq > 64 else "flat_scan_q64_d128")
+        _assert_same(D, I, D1, I1)
+        _assert_same(D, I, *oracle.flat_search(xb, xq, k, metric))
+
+
 def test_per_wave_publications_with_adversarial_order(gpu_faiss, oracle):
     """every chunk's first tile holds its worst rows, the best rows of the database sit at its end: a loose bound, never a
     wrong one (k = 1000, four keys per workgroup)"""

@@ -18,7 +18,8 @@ torch.cuda.set_device(0)
 g = torch.Generator(device=dev)
 g.manual_seed(9)
 d, k = 1024, 100
-sizes = [int(a) for a in sys.argv[1:]] or [10_000, 30_000, 65_536, 100_000, 200_000, 300_000, 400_000, 500_000, 524_288, 600_000, 800_000,
+NQS = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("nq=")] or [32, 1024]
+sizes = [int(a) for a in sys.argv[1:] if "=" not in a] or [10_000, 30_000, 65_536, 100_000, 200_000, 300_000, 400_000, 500_000, 524_288, 600_000, 800_000,
                                           1_000_000, 1_250_000, 2_000_000, 3_000_000, 5_000_000]
 index = ShardedFlatIndex(d, faiss.METRIC_INNER_PRODUCT, rank=0, world=1, row_offset=0)
 index.reserve(max(sizes))
@@ -32,7 +33,7 @@ for nb in sizes:
         have += m
         del x
     torch.cuda.synchronize()
-    for nq in (32, 1024):
+    for nq in NQS:
         q = torch.randn((nq, d), generator=g, device=dev)
         best = None
         steps = max(3, min(60, int(0.15 / max(1e-4, nb * (7e-10 if nq == 32 else 1.6e-8)))))
