@@ -2891,7 +2891,7 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
         const bool force = (h->flags & 128) != 0;
         const int64_t S = view_rows(nb, st, 0);
         const int j = stat_seed_rank(S, nb, k);
-        if (j > 0 && (force || (nq >= 1024 && nb >= 8192))) {
+        if (j > 0 && (force || (nq >= dev_knob("KNN355_STAT_MIN_NQ", 65) && nb >= 8192))) {
             // worth it only if it removes most of the candidates an unseeded pass would collect
             ScanPlan un;
             make_plan(h, nb, nq, k, false, un);
@@ -3334,7 +3334,7 @@ extern "C" int knn_merge_keys_dev(knn_handle h, const uint64_t *keys_dev, int32_
 static bool self_search_symmetric_eligible(const knn_index_s *h, int k, int *j_out = nullptr, int *qcap_out = nullptr)
 {
     const int64_t n = h->ntotal;
-    if (n < 8192 || k > KNN_REGISTER_SELECT_MAX_K || k >= n || (h->flags & (8 | 16 | 512 | 1024)) || h->force_qt || h->force_chunks || h->approx16) return false;
+    if (n < dev_knob("KNN355_SYM_MIN_N", 3000) || k > KNN_REGISTER_SELECT_MAX_K || k >= n || (h->flags & (8 | 16 | 512 | 1024)) || h->force_qt || h->force_chunks || h->approx16) return false;
     int st = n >= (1 << 20) ? 64 : 32;
 #ifdef KNN355_DEV
     if (getenv("KNN355_STAT_STRIDE")) st = atoi(getenv("KNN355_STAT_STRIDE"));
@@ -3382,7 +3382,7 @@ static int self_search_symmetric(knn_index_s *h, int k, float *D_dev, int64_t *I
     if (h->sym_tiles != T || !h->ws_sym.p) {
         int best_tp = 16;
         int64_t best_cost = INT64_MAX;
-        for (int tp = 6; tp <= 96; tp++) {
+        for (int tp = dev_knob("KNN355_SYM_MIN_TP", 1); tp <= 96; tp++) {
             int64_t wgs = 0;
             for (int I = 0; I < T; I++) wgs += (T - I + tp - 1) / tp;
             const int64_t rounds = (wgs + slots - 1) / slots;

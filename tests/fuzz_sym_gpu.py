@@ -20,8 +20,9 @@ fails = 0
 t0 = time.time()
 for case in range(ncases):
     d = int(rng.choice([8, 31, 32, 64, 100, 128, 256, 1024]))
-    n = int(rng.choice([8192, 8193, 9000, 12799, 12800, 14433, 20000, 33333])) if d < 1024 else int(rng.choice([8192, 14433]))
-    k = int(rng.choice([1, 2, 10, 11, 100, 101, 301, 512, 1000, 1536]))
+    n = int(rng.choice([3000, 3001, 4096, 5000, 6143, 8192, 8193, 9000, 12799, 12800, 14433, 20000, 33333])) if d < 1024 else int(rng.choice([3000, 8192, 14433]))
+    k = 0
+    k = min(n - 1, int(rng.choice([1, 2, 10, 11, 100, 101, 301, 512, 1000, 1400, 1536])))
     metric = int(rng.integers(0, 2))
     kind = int(rng.integers(0, 5))
     if kind == 0:

@@ -872,6 +872,50 @@ def test_batches_of_65_to_128_queries_on_a_mid_sized_database_go_as_two_pieces(g
         _assert_same(D, I, *oracle.flat_search(xb, xq, k, metric))
 
 
+@pytest.mark.parametrize("metric,nb,d,nq,k", [(0, 50_000, 32, 256, 1000), (1, 50_000, 24, 129, 100), (0, 200_000, 16, 700, 1000), (1, 9_000, 48, 512, 300),
+                                              (0, 300_000, 16, 128, 1000), (1, 400_000, 16, 100, 700)])
+def test_statistical_seed_serves_batches_from_65_queries_on(gpu_faiss, oracle, metric, nb, d, nq, k):
+    """129 .. 1023 queries used to run unseeded, with few long chunks so that every chunk's warm-up was amortised (50 k rows
+    x 256 queries, k = 1000: 38 workgroups, 2.4 ms); now the statistical seed (verified, repaired on failure) serves them
+    too: 0.52 ms.  Same bits as the oracle and as the unseeded search (flags 8)."""
+    rng = np.random.default_rng(nb + nq + k)
+    xb = rng.standard_normal((nb, d), dtype=np.float32)
+    xb[nb // 3: nb // 3 + 400] = xb[:400]
+    xq = rng.standard_normal((nq, d), dtype=np.float32)
+    xq[:3] = xb[5:8]
+    idx = gpu_faiss.IndexFlat(d, metric)
+    idx.add(xb)
+    D, I = idx.search(xq, k)
+    assert idx.last_seed()["stat_rank"] > 0, (idx.last_seed(), idx.last_scan())
+    Do, Io = oracle.flat_search(xb, xq, k, metric)
+    _assert_same(D, I, Do, Io)
+    idx.set_tuning(0, 0, 8)
+    D2, I2 = idx.search(xq, k)
+    assert idx.last_seed()["stat_rank"] == 0
+    _assert_same(D2, I2, Do, Io)
+
+
+@pytest.mark.parametrize("metric,n,d,k", [(0, 3000, 64, 11), (1, 3001, 32, 301), (0, 4096, 48, 1001), (1, 5000, 64, 100), (0, 7000, 32, 301), (1, 2999, 32, 50)])
+def test_symmetric_self_search_from_3000_rows_on(gpu_faiss, oracle, metric, n, d, k):
+    """The symmetric launch (runs of one tile on, so that a small index still fills the chip) serves whole-index
+    self-searches from 3000 rows on (before: 8192; 5000 rows: 0.81 -> 0.54 ms).  Same bits as the plain launch and as
+    the oracle on every row."""
+    rng = np.random.default_rng(n + k)
+    cent = rng.standard_normal((20, d), dtype=np.float32)
+    x = (cent[np.sort(rng.integers(0, 20, n))] + 0.4 * rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
+    x[n // 2: n // 2 + 50] = x[:50]
+    idx = gpu_faiss.IndexFlat(d, metric)
+    idx.add(x)
+    D, I = idx.search_self(k)
+    assert idx.last_scan()["kernel"].endswith("_sym") == (n >= 3000), idx.last_scan()
+    Do, Io = oracle.flat_search(x, x, k, metric, l2_mode=1)
+    _assert_same(D, I, Do, Io)
+    idx.set_tuning(0, 0, 1024)
+    Dp, Ip = idx.search_self(k)
+    assert not idx.last_scan()["kernel"].endswith("_sym")
+    _assert_same(Dp, Ip, Do, Io)
+
+
 def test_per_wave_publications_with_adversarial_order(gpu_faiss, oracle):
     """every chunk's first tile holds its worst rows, the best rows of the database sit at its end: a loose bound, never a
     wrong one (k = 1000, four keys per workgroup)"""
