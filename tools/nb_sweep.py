@@ -21,7 +21,8 @@ d, k = 1024, 100
 NQS = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("nq=")] or [32, 1024]
 sizes = [int(a) for a in sys.argv[1:] if "=" not in a] or [10_000, 30_000, 65_536, 100_000, 200_000, 300_000, 400_000, 500_000, 524_288, 600_000, 800_000,
                                           1_000_000, 1_250_000, 2_000_000, 3_000_000, 5_000_000]
-index = ShardedFlatIndex(d, faiss.METRIC_INNER_PRODUCT, rank=0, world=1, row_offset=0)
+METRIC = faiss.METRIC_L2 if "metric=l2" in sys.argv else faiss.METRIC_INNER_PRODUCT
+index = ShardedFlatIndex(d, METRIC, rank=0, world=1, row_offset=0)
 index.reserve(max(sizes))
 have = 0
 for nb in sizes:
