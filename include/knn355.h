@@ -324,6 +324,13 @@ int knn_flat_set_batch(knn_handle h, int64_t nq_whole);
  * percent, the 8 TB/s of the data sheet is not reached by any kernel. */
 int knn_flat_read_rate(knn_handle h, int32_t reps, float *best_ms, int64_t *bytes_read);
 
+/* Measurement aid (bench.py's batch roofline): what THIS box's fp32 matrix pipes sustain -- every wave issues
+ * back-to-back v_mfma_f32_32x32x2_f32 on independent accumulators, operands in registers (random values), two
+ * workgroups per CU, no memory traffic.  Launches run back to back for warm_ms milliseconds first (the chip settles on
+ * the clock it holds under this load), then the best of eight is reported: tflops, and clock_mhz (may be NULL) = the
+ * in-kernel shader clock of that launch.  The data sheet's dense fp32 MFMA peak is 157.3 TFLOP/s at 2.4 GHz. */
+int knn_mfma_rate(int32_t warm_ms, float *tflops, float *clock_mhz);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,6 +65,7 @@ def _declare(L):
         "knn_set_tuning": (c_int32, [H, c_int32, c_int32, c_int32]),
         "knn_flat_set_batch": (c_int32, [H, c_int64]),
         "knn_flat_read_rate": (c_int32, [H, c_int32, POINTER(c_float), POINTER(c_int64)]),
+        "knn_mfma_rate": (c_int32, [c_int32, POINTER(c_float), POINTER(c_float)]),
         "knn_hnsw_create": (c_int32, [c_int32, c_int32, c_int32, POINTER(H)]),
         "knn_hnsw_set_ef": (c_int32, [H, c_int32, c_int32]),
         "knn_hnsw_set_walk": (c_int32, [H, c_int32, c_int32]),

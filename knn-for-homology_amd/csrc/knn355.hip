@@ -783,8 +783,10 @@ __device__ __forceinline__ void lists_compact(ListCtx &L, char *smem, int tile_r
                     const int cnt2 = select(lst, m, kmax, &T);
                     if (lane == 0) {
                         L.s_cnt[ql] = cnt2;
-                        L.s_thr[ql] = ord2f(T);
-                        atomicMin(&L.gthr[ql], T);
+                        if (T != 0xFFFFFFFFu) { // (0xFFFFFFFF: the list held no more than kmax real keys beside its KEY_PAD entries -- no bound, and ord2f of it is a NaN)
+                            L.s_thr[ql] = ord2f(T);
+                            atomicMin(&L.gthr[ql], T);
+                        }
                     }
                     continue;
                 }
@@ -792,8 +794,10 @@ __device__ __forceinline__ void lists_compact(ListCtx &L, char *smem, int tile_r
             const int cnt = select(lst, n, kmax, &T);
             if (lane == 0) {
                 L.s_cnt[ql] = cnt;
-                L.s_thr[ql] = ord2f(T);
-                atomicMin(&L.gthr[ql], T);
+                if (T != 0xFFFFFFFFu) { // (see above: a cut that fell into the padding gives no bound)
+                    L.s_thr[ql] = ord2f(T);
+                    atomicMin(&L.gthr[ql], T);
+                }
             }
         }
         __syncthreads();
@@ -3258,7 +3262,12 @@ static int search_failed(knn_index_s *h, bool *failed)
     int flag = 0;
     HIP_TRY(hipMemcpy(&flag, h->ws_flag.p, 4, hipMemcpyDeviceToHost));
     *failed = flag != 0;
-    if (flag) h->stat_redo++;
+    if (flag) {
+        h->stat_redo++;
+        // read = cleared: a search whose predecessor left the level's state reset (LevelBufs::clean_sig) skips the launch
+        // that clears the flag, and a repeat that returns early with an error never reaches its own
+        HIP_TRY(hipMemset(h->ws_flag.p, 0, 4));
+    }
     return 0;
 }
 
@@ -3469,6 +3478,7 @@ static int self_search_symmetric(knn_index_s *h, int k, float *D_dev, int64_t *I
     sp.qthr = qthr; sp.fail = (int *)h->ws_flag.p;
     rc = launch_select(sp, s, &h->ws_tmp);
     if (rc) return rc;
+    if (h->done) (void)hipEventRecord(h->done, s); // (everything this search enqueued on the handle's buffers: see DevBuf::ensure)
     h->sym_searches++;
     return 1;
 }
@@ -3903,6 +3913,102 @@ extern "C" int knn_flat_read_rate(knn_handle h, int32_t reps, float *best_ms, in
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     *best_ms = best;
+    return 0;
+}
+
+// ---- measurement aid: the box's fp32 MFMA rate -----------------------------------------------------------------
+// every wave issues back-to-back v_mfma_f32_32x32x2_f32 on four independent accumulators, operands in registers, no
+// memory traffic: what the matrix pipes of THIS box sustain under load (the chip lowers its clock: the in-kernel clock is
+// d(s_memtime) / d(s_memrealtime) x 100 MHz), to set beside the data sheet's 157.3 TFLOP/s
+__global__ __launch_bounds__(256) void mfma_rate_kernel(float *out, int iters, unsigned long long *clk)
+{
+    float x[8], y[8];
+    unsigned s0 = (blockIdx.x * 256u + threadIdx.x) * 16u;
+    for (int i = 0; i < 16; i++) { // (random operands: constant ones toggle fewer wires and run at a higher clock than real data)
+        unsigned s = (s0 + i) * 747796405u + 2891336453u;
+        s = ((s >> ((s >> 28) + 4)) ^ s) * 277803737u;
+        s = (s >> 22) ^ s;
+        const float v = (float)(s & 0xFFFFFF) / 8388608.0f - 1.0f;
+        if (i < 8) x[i] = v;
+        else y[i - 8] = v;
+    }
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    f32x16 a0 = {}, a1 = {}, a2 = {}, a3 = {};
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[u], y[u], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[u + 1], y[u], a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[u], y[u + 1], a2, 0, 0, 0);
+            a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[u + 1], y[u + 1], a3, 0, 0, 0);
+        }
+    }
+    float s = 0.0f;
+    for (int r = 0; r < 16; r++) s += a0[r] + a1[r] + a2[r] + a3[r];
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (s == 12345.678f) out[0] = s; // (keeps the accumulators alive)
+    if (threadIdx.x == 0) {
+        clk[2 * blockIdx.x] = t1 - t0;
+        clk[2 * blockIdx.x + 1] = r1 - r0;
+    }
+}
+
+extern "C" int knn_mfma_rate(int32_t warm_ms, float *tflops, float *clock_mhz)
+{
+    if (!tflops) return set_err(KNN_ERR_INVALID, "mfma_rate: null pointer");
+    int rc = ensure_device(g_device);
+    if (rc) return rc;
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, g_device);
+    const int grid = 2 * std::max(1, cus), iters = 8000; // (two workgroups per CU: two waves per SIMD, as in the scan)
+    size_t got_o = 0, got_c = 0;
+    float *o = (float *)pool_alloc(64, g_device, &got_o);
+    unsigned long long *c = (unsigned long long *)pool_alloc((size_t)grid * 16, g_device, &got_c);
+    hipStream_t s = g_streams.take(g_device);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto cleanup = [&]() {
+        if (s) { (void)hipStreamSynchronize(s); g_streams.give(g_device, s); }
+        if (o) g_pool.give(o, got_o, g_device);
+        if (c) g_pool.give(c, got_c, g_device);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    };
+    if (!o || !c || !s || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        cleanup();
+        return set_err(KNN_ERR_HIP, "mfma_rate: out of resources");
+    }
+    // back-to-back launches until warm_ms of them have run (the clock settles under load), then the best of eight
+    const double flop = (double)grid * 4 /* waves */ * iters * 16.0 * (32.0 * 32 * 2 * 2);
+    float best = FLT_MAX, total = 0.0f;
+    double mhz = 0.0;
+    std::vector<unsigned long long> hc((size_t)grid * 2);
+    int timed = 0;
+    for (int r = 0; r < 4000 && timed < 8; r++) {
+        hipError_t e = hipEventRecord(e0, s);
+        hipLaunchKernelGGL(mfma_rate_kernel, dim3(grid), dim3(256), 0, s, o, iters, c);
+        if (e == hipSuccess) e = hipEventRecord(e1, s);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.0f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e != hipSuccess) {
+            cleanup();
+            return set_err(KNN_ERR_HIP, std::string("mfma_rate: ") + hipGetErrorString(e));
+        }
+        total += ms;
+        if (total < (float)warm_ms) continue;
+        timed++;
+        if (ms < best) {
+            best = ms;
+            if (hipMemcpy(hc.data(), c, hc.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                double acc = 0.0;
+                for (int b = 0; b < grid; b++) acc += (double)hc[2 * b] / (double)std::max<unsigned long long>(1, hc[2 * b + 1]) * 100.0;
+                mhz = acc / grid;
+            }
+        }
+    }
+    cleanup();
+    *tflops = (float)(flop / (best * 1e-3) / 1e12);
+    if (clock_mhz) *clock_mhz = (float)mhz;
     return 0;
 }
 

@@ -58,15 +58,15 @@ def build_index(index_mode: str, d: int):
 
 def run(embeddings: numpy.ndarray, index_mode: str, data_dir: Path, npy_size: int, k: int = K):
     """pfam/proteins_search.py:21-57 on an array already loaded and cast: normalises ``embeddings`` IN PLACE
-    (:22 ``faiss.normalize_L2(embeddings)``), builds / writes the index, searches, saves."""
+    (:22 ``faiss.normalize_L2(embeddings)``), builds / writes the index, searches, saves.  ``embeddings`` may be a
+    callable that loads the array: the ranks that only wait (HNSW / LSH under a multi-rank launch) never call it."""
     if index_mode != "flat" and ranks.launched_group()[1] > 1:  # (also: this rank's GPU is chosen before the first device call)
         # HNSW and LSH do not shard (SURVEY.md 8(e): replicas only): under a multi-rank launch rank 0 runs them on its
         # GPU, the other ranks wait for its files
-        result = None
-        if ranks.writer():
-            result = _run(embeddings, index_mode, data_dir, npy_size, k, print, lambda: None)
-        ranks.barrier()
-        return result
+        # (ranks.rank0_only: they wait for its outcome -- an error on rank 0 raises everywhere)
+        return ranks.rank0_only(lambda: _run(embeddings() if callable(embeddings) else embeddings, index_mode, data_dir, npy_size, k, print, lambda: None))
+    if callable(embeddings):
+        embeddings = embeddings()
     return _run(embeddings, index_mode, data_dir, npy_size, k, print if ranks.writer() else (lambda *a, **kw: None), ranks.barrier)
 
 
@@ -116,10 +116,16 @@ def main(argv: Optional[Sequence[str]] = None, data_dir: Optional[Path] = None, 
     index_mode = argv[1]
     data_dir = Path(data_dir) if data_dir is not None else _default_dir()
     npy = data_dir / "full_sequences.npy"
-    embeddings = numpy.load(npy).astype(numpy.float32)
-    if ranks.writer():
-        print("full_sequences", embeddings.shape)
-    run(embeddings, index_mode, data_dir, npy.stat().st_size, k)
+
+    def load():
+        embeddings = numpy.load(npy).astype(numpy.float32)
+        if ranks.writer():
+            print("full_sequences", embeddings.shape)
+        return embeddings
+
+    # (HNSW / LSH under a multi-rank launch: the ranks that only wait for rank 0 do not load 0.8 GB to sit beside it)
+    waits = index_mode in ("lsh", "hnsw") and ranks.launched_group()[1] > 1 and not ranks.writer()
+    run(load if waits else load(), index_mode, data_dir, npy.stat().st_size, k)
 
 
 if __name__ == "__main__":

@@ -37,19 +37,22 @@ def _filled(index, rows):
     return index
 
 
-def _search_and_store(folder: Path, stem: str, index, queries, k: int):
+def _search_and_store(folder: Path, stem: str, index, queries, k: int, sync: bool = True):
     """``<stem>_scores.npy`` / ``<stem>_hits.npy`` in the embedding set's directory."""
     scores, hits = index.search(queries, k)
     if ranks.writer():  # (multi-rank launch: every rank has the gathered arrays, rank 0 writes them)
         for suffix, array in (("scores", scores), ("hits", hits)):
             numpy.save(folder / f"{stem}_{suffix}.npy", array)
-    ranks.barrier()
+    if sync:
+        ranks.barrier()
 
 
 def search_index(embedding_set: Path, k: int = K):
-    if not ranks.writer():  # (LSH does not shard: rank 0 of a multi-rank launch runs it alone)
-        ranks.barrier()
-        return
+    # (LSH does not shard: rank 0 of a multi-rank launch runs it alone, the others wait for its outcome without loading anything)
+    ranks.rank0_only(lambda: _search_index(embedding_set, k))
+
+
+def _search_index(embedding_set: Path, k: int):
     folder = Path(embedding_set)
     train, test = load_embeddings(folder)
     cached = folder / f"index_lsh_{LSH_BITS}.bin"
@@ -58,7 +61,7 @@ def search_index(embedding_set: Path, k: int = K):
     else:
         lsh = _filled(faiss.IndexLSH(train.shape[1], LSH_BITS), train)
         faiss.write_index(lsh, str(cached))
-    _search_and_store(folder, "index", lsh, test, k)
+    _search_and_store(folder, "index", lsh, test, k, sync=False)
 
 
 def search_flat(embedding_set: Path, k: int = K):

@@ -54,3 +54,24 @@ def same_everywhere(obj):
     box = [obj]
     dist.broadcast_object_list(box, src=0)
     return box[0]
+
+
+def rank0_only(work):
+    """``work()`` on rank 0 alone (HNSW and LSH do not shard: SURVEY.md 8(e), replicas only); the other ranks wait for
+    its OUTCOME, not at a bare barrier: rank 0 broadcasts "done" or its error text, and a failure raises on every rank
+    instead of leaving the others in a collective until its timeout.  Returns work()'s value on rank 0, None elsewhere."""
+    rank, world = launched_group()
+    if world == 1:
+        return work()
+    result, failure, text = None, None, None
+    if rank == 0:
+        try:
+            result = work()
+        except BaseException as e:  # noqa: BLE001 -- the peers must hear about it whatever it is
+            failure, text = e, f"{type(e).__name__}: {e}"
+    text = same_everywhere(text)
+    if failure is not None:
+        raise failure
+    if text is not None:
+        raise RuntimeError(f"rank 0 failed: {text}")
+    return result

@@ -21,6 +21,7 @@ all-gather of one search run beside the scan of the other.  ``search_dev`` = sub
 torch is used for device memory, streams and torch.distributed only.
 """
 import ctypes
+import datetime
 import os
 
 import numpy as np
@@ -49,10 +50,12 @@ def launched_group():
     device = 0 if rehearse else local
     torch.cuda.set_device(device)
     _lib.check(_lib.lib().knn_init(device))
+    # (a rank that waits for rank 0's HNSW build or for a slow peer must outlive the 10-minute default)
+    timeout = datetime.timedelta(seconds=float(os.environ.get("KNN355_DIST_TIMEOUT_S", "7200")))
     if rehearse:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timeout)
     else:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device), timeout=timeout)
     return rank, world
 
 
@@ -112,9 +115,12 @@ class HipShardBackend:
         return self.index.ntotal
 
     # the three device steps; `index` picks the lane, the launches go to torch's CURRENT stream
-    def search_keys(self, q: torch.Tensor, k: int, id_base: int, index=None) -> torch.Tensor:
+    def search_keys(self, q: torch.Tensor, k: int, id_base: int, index=None, out=None) -> torch.Tensor:
+        """k packed keys per query; ``out``: a contiguous [nq, k] int64 tensor to write them into (the front of the
+        all-gather's send buffer)"""
         nq = q.shape[0]
-        keys = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+        keys = out if out is not None else torch.empty((nq, k), dtype=torch.int64, device=q.device)
+        assert keys.is_contiguous() and keys.shape == (nq, k) and keys.dtype == torch.int64
         cur = torch.cuda.current_stream(q.device)
         stream = cur.cuda_stream
         if stream == 0:
@@ -159,20 +165,49 @@ class HipShardBackend:
         return D, I
 
 
+class ShardSearchError(RuntimeError):
+    """A sharded search failed on at least one rank; raised on EVERY rank (``failed_ranks``: who)."""
+
+    def __init__(self, failed_ranks, local=None):
+        self.failed_ranks = list(failed_ranks)
+        msg = f"sharded search failed on rank(s) {self.failed_ranks}"
+        if local is not None:
+            msg += f"; this rank: {type(local).__name__}: {local}"
+        super().__init__(msg)
+
+
 class PendingSearch:
     """Result of ``ShardedFlatIndex.submit``: ``result()`` makes the caller's current stream
-    wait for the search and hands out (D, I)."""
+    wait for the search and hands out (D, I).
 
-    def __init__(self, D, I, event=None):
+    A search over several ranks carries a status row through its all-gather (see
+    ``ShardedFlatIndex._search_on_current_stream``): ``result()`` reads it (k x 8 bytes to the host, so the call waits
+    for the search) and raises ``ShardSearchError`` on every rank if any rank's local scan failed.  ``result(check=False)``
+    only orders the streams; ``check()`` can be called later."""
+
+    def __init__(self, D, I, event=None, status=None, local_error=None):
         self._D, self._I, self._event = D, I, event
+        self._status, self._local_error = status, local_error
 
-    def result(self):
+    def check(self):
+        if self._status is not None:
+            st = self._status.cpu()
+            self._status = None
+            failed = [int(r) for r in st.tolist() if r >= 0]
+            if failed or self._local_error is not None:
+                raise ShardSearchError(failed, self._local_error) from self._local_error
+
+    def result(self, check=True):
         if self._event is not None:
             cur = torch.cuda.current_stream(self._D.device)
             cur.wait_event(self._event)
             self._D.record_stream(cur)
             self._I.record_stream(cur)
+            if self._status is not None:
+                self._status.record_stream(cur)
             self._event = None
+        if check:
+            self.check()
         return self._D, self._I
 
 
@@ -213,22 +248,39 @@ class ShardedFlatIndex:
         self.backend.add(x)
 
     def _search_on_current_stream(self, q, k, index=None):
+        """-> (D, I, status, local_error).  Several ranks: the all-gather's send buffer is [nq + 1, k] keys -- the rank's
+        k best keys per query and one STATUS row, all padding on a healthy rank.  A rank whose local scan raises (out of
+        memory, a stale view, a bad argument -- anything the C ABI reports) still enters the collective, with "no rows"
+        for keys and its rank number as the one key of its status row: its peers neither hang in the all-gather nor
+        return a result that silently lacks a shard.  The merge treats the status row as one more query, so its output
+        row lists the failed ranks (ids, ascending; -1 = none): ``status``.  The same rule as the library's own
+        ``knn_sharded_search_dev`` (enter the collective with padding, report afterwards)."""
         kw = {"index": index} if index is not None else {}
         if self.world == 1 and not self.force_collective:
-            return self.backend.search(q, k, **kw)
+            D, I = self.backend.search(q, k, **kw)
+            return D, I, None, None
         nq = q.shape[0]
-        keys = self.backend.search_keys(q, k, self.row_offset, **kw)
-        # rank-major concatenation along dim 0 == [world, nq, k]
-        gathered = torch.empty((self.world * nq, k), dtype=torch.int64, device=keys.device)
-        timed = self.collective_events is not None and keys.is_cuda
+        dev = getattr(self.backend, "device", q.device)
+        send = torch.full((nq + 1, k), -1, dtype=torch.int64, device=dev)  # (-1 = KEY_PAD: no key)
+        local_error = None
+        try:
+            self.backend.search_keys(q, k, self.row_offset, out=send[:nq], **kw)
+        except Exception as e:  # noqa: BLE001 -- whatever it is, the peers are about to enter the collective
+            local_error = e
+            send[:nq].fill_(-1)
+            send[nq, 0] = self.rank  # (score word 0, id = rank: sorts in front of any padding)
+        # rank-major concatenation along dim 0 == [world, nq + 1, k]
+        gathered = torch.empty((self.world * (nq + 1), k), dtype=torch.int64, device=send.device)
+        timed = self.collective_events is not None and send.is_cuda
         if timed:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        dist.all_gather_into_tensor(gathered, keys, group=self.group)
+        dist.all_gather_into_tensor(gathered, send, group=self.group)
         if timed:
             ev1.record()
             self.collective_events.append((ev0, ev1))
-        return self.backend.merge(gathered.view(self.world, nq, k), self.world, nq, k, **kw)
+        D, I = self.backend.merge(gathered.view(self.world, nq + 1, k), self.world, nq + 1, k, **kw)
+        return D[:nq], I[:nq], I[nq], local_error
 
     def submit(self, q, k) -> PendingSearch:
         """Enqueues one search of q ([nq, d] float32, identical on every rank) and returns at once.
@@ -240,18 +292,21 @@ class ShardedFlatIndex:
         k = int(k)
         lanes = getattr(self.backend, "next_lane", None)
         if lanes is None:  # a backend without device streams (the CPU test backend)
-            return PendingSearch(*self._search_on_current_stream(q, k))
+            D, I, status, err = self._search_on_current_stream(q, k)
+            return PendingSearch(D, I, None, status, err)
         index, side = lanes()
         side.wait_stream(torch.cuda.current_stream(q.device))
         q.record_stream(side)
         with torch.cuda.stream(side):
-            D, I = self._search_on_current_stream(q, k, index)
+            D, I, status, err = self._search_on_current_stream(q, k, index)
             done = side.record_event()
-        return PendingSearch(D, I, done)
+        return PendingSearch(D, I, done, status, err)
 
     def search_dev(self, q, k):
         """q: [nq, d] float32 tensor, identical on every rank.  Returns (D, I) tensors holding the
-        global result on every rank, ordered after the search on the caller's current stream."""
+        global result on every rank, ordered after the search on the caller's current stream.  Over several ranks the
+        call waits for the search's status row (``PendingSearch.result``) and raises ``ShardSearchError`` on every rank
+        if any rank failed; ``submit(...).result(check=False)`` stays asynchronous."""
         return self.submit(q, k).result()
 
     def search(self, x: np.ndarray, k):
@@ -318,6 +373,9 @@ class QueryShardedFlatIndex:
         k = int(k)
         nq = q.shape[0]
         lo, hi = self.query_bounds(nq)
+        local_error = None
+        D = torch.empty((0, k), dtype=torch.float32, device=q.device)
+        I = torch.empty((0, k), dtype=torch.int64, device=q.device)
         if hi > lo:
             # (this rank's slice is a piece of the caller's batch: the L2 formula FAISS would pick for all nq queries)
             set_batch = getattr(getattr(self.backend, "index", None), "set_batch", None)
@@ -325,14 +383,16 @@ class QueryShardedFlatIndex:
                 set_batch(nq)
             try:
                 D, I = self.backend.search(q[lo:hi].contiguous(), k)
+            except Exception as e:  # noqa: BLE001
+                if not gather or self.world == 1:
+                    raise
+                local_error = e  # (the peers are about to enter the gathers: agree on the outcome first)
             finally:
                 if set_batch:
                     set_batch(0)
-        else:
-            D = torch.empty((0, k), dtype=torch.float32, device=q.device)
-            I = torch.empty((0, k), dtype=torch.int64, device=q.device)
         if not gather or self.world == 1:
             return D, I
+        self._agree(local_error, q.device)
         per = (nq + self.world - 1) // self.world
         Dp = torch.zeros((per, k), dtype=torch.float32, device=q.device)
         Ip = torch.full((per, k), -1, dtype=torch.int64, device=q.device)
@@ -344,6 +404,18 @@ class QueryShardedFlatIndex:
         dist.all_gather_into_tensor(Ig, Ip, group=self.group)
         # (contiguous slices of ceil(nq/world) queries: rank-major concatenation is query order)
         return Dg[:nq], Ig[:nq]
+
+    def _agree(self, local_error, device=None):
+        """In front of the result gathers: did every rank's slice succeed?  One all-gather of a flag per rank; a failure
+        anywhere raises ``ShardSearchError`` on EVERY rank instead of leaving the healthy ones inside the gathers."""
+        on_gpu = dist.get_backend(self.group) == "nccl"
+        dev = (device if device is not None and device.type == "cuda" else getattr(self.backend, "device", torch.device("cpu"))) if on_gpu else torch.device("cpu")
+        flag = torch.tensor([0 if local_error is None else 1], dtype=torch.int32, device=dev)
+        flags = torch.empty((self.world,), dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(flags, flag, group=self.group)
+        failed = [r for r, f in enumerate(flags.cpu().tolist()) if f]
+        if failed:
+            raise ShardSearchError(failed, local_error) from local_error
 
     def normalize_rows(self):
         """L2-normalises the replica's rows in HBM (every rank: the same rows, the same bits)"""
@@ -359,16 +431,21 @@ class QueryShardedFlatIndex:
         set_batch = getattr(getattr(self.backend, "index", None), "set_batch", None)
         if set_batch:
             set_batch(n)  # (the slice is a piece of an n-query batch: FAISS's choice of the L2 formula)
+        local_error = None
+        D, I = np.empty((0, k), np.float32), np.empty((0, k), np.int64)
         try:
             if hi > lo:
                 D, I = self.backend.search_self(k, lo, hi - lo)
-            else:
-                D, I = np.empty((0, k), np.float32), np.empty((0, k), np.int64)
+        except Exception as e:  # noqa: BLE001
+            if not gather or self.world == 1:
+                raise
+            local_error = e
         finally:
             if set_batch:
                 set_batch(0)
         if not gather or self.world == 1:
             return D, I
+        self._agree(local_error)
         per = (n + self.world - 1) // self.world
         # gloo gathers host tensors, RCCL device tensors
         on_gpu = dist.get_backend(self.group) == "nccl"

@@ -148,9 +148,8 @@ def test_index_hnsw_flat_bytes(gpu_faiss, tmp_path):
     # the graph is connected at level 0: with ef >= n the walk returns the exact neighbours
     idx.hnsw.efSearch = 16
     D, I = idx.search(rows, 3)
-    flat = gpu_faiss.IndexFlat(4, 1)
-    flat.set_tuning(0, 0, 32)  # (the norm formula: what the walk's rows are re-scored with)
-    flat.add(rows)
+    flat = gpu_faiss.IndexFlat(4, 1)  # (6 queries: FAISS's small-batch squared L2, the sum of squared differences -- what the
+    flat.add(rows)                    # HNSW index scores with at every batch size, as FAISS's HNSW distance computer does)
     Df, If = flat.search(rows, 3)
     assert np.array_equal(I, If) and np.array_equal(D.view(np.uint32), Df.view(np.uint32))
 

@@ -47,12 +47,20 @@ class OracleShardBackend:
     def ntotal(self):
         return self.rows.shape[0]
 
-    def search_keys(self, q, k, id_base):
+    fail_search_keys = None  # (tests: an exception instance the next local scan raises)
+
+    def search_keys(self, q, k, id_base, out=None):
+        if self.fail_search_keys is not None:
+            raise self.fail_search_keys
         D, I = self.ko.oracle().flat_search(self.rows, q.numpy(), k, self.metric)
         v = -D if self.metric == 0 else D
         keys = (_f2ord(v + np.float32(0)) << np.uint64(32)) | (I.astype(np.uint64) + np.uint64(id_base))
         keys[I < 0] = np.uint64(0xFFFFFFFFFFFFFFFF)
-        return torch.from_numpy(keys.view(np.int64))
+        keys = torch.from_numpy(keys.view(np.int64))
+        if out is not None:
+            out.copy_(keys)
+            return out
+        return keys
 
     def search(self, q, k):
         D, I = self.ko.oracle().flat_search(self.rows, q.numpy(), k, self.metric)
@@ -95,6 +103,60 @@ def _worker(rank, world, port, metric, out_dir):
     idx.add(xb[lo:hi])
     D, I = idx.search(xq, 25)
     np.savez(Path(out_dir) / f"r{rank}.npz", D=D, I=I)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _worker_failing(rank, world, port, out_dir):
+    """rank 1's local scan raises: every rank must come out of the search with ShardSearchError naming rank 1 -- nobody
+    hangs in the all-gather, nobody returns a result that lacks a shard -- and the NEXT search works again"""
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    from knn_for_homology_amd.sharded import ShardedFlatIndex, QueryShardedFlatIndex, ShardSearchError, shard_bounds
+    from test_sharded_cpu import OracleShardBackend
+    rng = np.random.default_rng(80)
+    xb = rng.standard_normal((400, 32), dtype=np.float32)
+    xq = rng.standard_normal((7, 32), dtype=np.float32)
+    lo, hi = shard_bounds(400, world, rank)
+    idx = ShardedFlatIndex(32, 0, row_offset=lo, backend=OracleShardBackend(32, 0))
+    idx.add(xb[lo:hi])
+    if rank == 1:
+        idx.backend.fail_search_keys = MemoryError("search: out of device memory (test)")
+    res = {}
+    try:
+        idx.search(xq, 5)
+        res["raised"] = 0
+    except ShardSearchError as e:
+        res["raised"] = 1
+        res["failed_ranks"] = np.array(e.failed_ranks)
+        res["has_local"] = int("out of device memory" in str(e))
+    # asynchronous form: nothing raises until the status row is looked at
+    pending = idx.submit(torch.from_numpy(xq), 5)
+    D, I = pending.result(check=False)
+    try:
+        pending.check()
+        res["raised_async"] = 0
+    except ShardSearchError:
+        res["raised_async"] = 1
+    idx.backend.fail_search_keys = None
+    D, I = idx.search(xq, 5)
+    res["D"], res["I"] = D, I
+    # the query-sharded index with gather: the same agreement in front of its gathers
+    qs = QueryShardedFlatIndex(32, 0, backend=OracleShardBackend(32, 0))
+    qs.add(xb)
+    if rank == 1:
+        qs.backend.search = lambda *a, **kw: (_ for _ in ()).throw(RuntimeError("boom"))
+    try:
+        qs.search(xq, 5)
+        res["qs_raised"] = 0
+    except ShardSearchError as e:
+        res["qs_raised"] = 1
+        res["qs_failed"] = np.array(e.failed_ranks)
+    np.savez(Path(out_dir) / f"f{rank}.npz", **res)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -250,6 +312,53 @@ def test_three_rank_query_sharded_all_vs_all(tmp_path, metric):
         assert np.array_equal(got["Il"], Io[lo:hi]) and np.array_equal(got["Dl"].view(np.uint32), Do[lo:hi].view(np.uint32))
         assert np.array_equal(got["I1"], I1o) and np.array_equal(got["D1"].view(np.uint32), D1o.view(np.uint32))
     assert seen == [(0, 101), (101, 202), (202, 301)]
+
+
+def test_a_failing_rank_raises_on_every_rank(tmp_path):
+    """a local failure on one rank enters the collective with padding + a status row; every rank
+    raises, none hangs, the index stays usable."""
+    from oracle import knn_oracle as ko
+    mp.spawn(_worker_failing, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    rng = np.random.default_rng(80)
+    xb = rng.standard_normal((400, 32), dtype=np.float32)
+    xq = rng.standard_normal((7, 32), dtype=np.float32)
+    Do, Io = ko.oracle().flat_search(xb, xq, 5, 0)
+    for r in range(2):
+        got = np.load(tmp_path / f"f{r}.npz")
+        assert got["raised"] == 1 and got["failed_ranks"].tolist() == [1], f"rank {r}"
+        assert got["has_local"] == (1 if r == 1 else 0)
+        assert got["raised_async"] == 1
+        assert np.array_equal(got["I"], Io) and np.array_equal(got["D"].view(np.uint32), Do.view(np.uint32)), "the search after the failure"
+        assert got["qs_raised"] == 1 and got["qs_failed"].tolist() == [1]
+
+
+def _worker_rank0_only(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from knn_for_homology_amd import ranks
+    out = {"ok": ranks.rank0_only(lambda: 41 + 1)}
+    try:
+        ranks.rank0_only(lambda: (_ for _ in ()).throw(ValueError("bad index")))
+        out["raised"] = ""
+    except Exception as e:  # noqa: BLE001
+        out["raised"] = f"{type(e).__name__}: {e}"
+    import json
+    (Path(out_dir) / f"z{rank}.json").write_text(json.dumps(out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank0_only_reports_rank0s_outcome_everywhere(tmp_path):
+    """HNSW / LSH modes run on rank 0 alone -- the waiting ranks must hear about a failure instead of
+    sitting in a barrier until the collective timeout."""
+    import json
+    mp.spawn(_worker_rank0_only, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    for r in range(3):
+        got = json.loads((tmp_path / f"z{r}.json").read_text())
+        assert got["ok"] == (42 if r == 0 else None)
+        assert got["raised"] == ("ValueError: bad index" if r == 0 else "RuntimeError: rank 0 failed: ValueError: bad index")
 
 
 def test_shard_bounds_cover_everything():

@@ -118,6 +118,11 @@ if bench_json.exists():
             traffic[kern]["database_bytes"] = n * 1024 * 4
     except Exception as e:  # pragma: no cover
         print("could not attach the batch workload:", e)
+# the counters belong to the kernels of ONE revision of the source: bench.py quotes them only while csrc/knn355.hip still
+# hashes to this (a kernel change that keeps the byte count kept quoting stale counters)
+import hashlib
+traffic["_meta"] = {"knn355_hip_sha256": hashlib.sha256((ROOT / "knn-for-homology_amd" / "csrc" / "knn355.hip").read_bytes()).hexdigest(),
+                    "round": tag, "collected_by": "tools/collect_profiles.sh + tools/summarize_profiles.py"}
 (out / "pmc_traffic.json").write_text(json.dumps(traffic, indent=1))
 print(open(out / f"{tag}_bench_kernel_stats.csv").read()[:1500])
 print(json.dumps(traffic, indent=1))
