@@ -242,9 +242,9 @@ def run(args):
         mine = [buf_ms[i] for i in range(n_ms) if buf_ms[i] > 0]
         box = torch.tensor([float(digest & 0xFFFFFFFF), float((digest >> 32) & 0xFFFFFFFF), float(np.mean(mine)) if mine else -1.0,
                             1.0 if (planted_ok and sorted_ok) else 0.0], dtype=torch.float64, device=dev)
-        allbox = torch.empty((world, 4), dtype=torch.float64, device=dev)
+        allbox = torch.empty((world * 4,), dtype=torch.float64, device=dev)  # (flat: gloo wants the concatenation's own shape)
         dist.all_gather_into_tensor(allbox, box)
-        ab = allbox.cpu().numpy()
+        ab = allbox.view(world, 4).cpu().numpy()
         digests = [int(r[0]) | (int(r[1]) << 32) for r in ab]
         scan_ms_ranks = [float(r[2]) for r in ab]
         planted_ok = bool(planted_ok and (ab[:, 3] == 1.0).all())
@@ -496,6 +496,15 @@ def nq_sweep(index, dev, L, _lib, d, k, nb):
         rows = nb - index.local.last_seed()["sample_rows"]  # rows the timed kernel scans (the seed sample has its own launch)
         by = passes * rows * d * 4 + nq * d * 4 + nq * k * 12
         fl = 2.0 * nq * rows * d
+        if nq > 1024:
+            # several launches (full 128-query tiles + the remainder on a narrower build): last_scan() describes the last one
+            # only -- the whole search's time is the denominator
+            passes = (nq + 127) // 128
+            rec = {"nq": nq, "queries_per_s": nq / t, "ms": 1e3 * t, "kernel": "flat_scan_q128_d128 (+ the remainder's launch)", "kernel_ms": None,
+                   "db_passes": passes, "hbm_frac": (passes * rows * d * 4 + nq * d * 4 + nq * k * 12) / t / 1e9 / HBM_PEAK_GBS,
+                   "mfma_frac": fl / t / 1e12 / FP32_MFMA_PEAK_TF, "bound": "mfma", "basis": "whole search (all launches, selections included)"}
+            res.append(rec)
+            continue
         rec = {"nq": nq, "queries_per_s": nq / t, "ms": 1e3 * t, "kernel": info["kernel"], "kernel_ms": sm, "db_passes": passes,
                "hbm_frac": by / (sm * 1e-3) / 1e9 / HBM_PEAK_GBS, "mfma_frac": fl / (sm * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF}
         rec["bound"] = "hbm" if passes == 1 else "mfma"

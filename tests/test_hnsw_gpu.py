@@ -229,7 +229,7 @@ def test_upper_levels_are_linked_on_a_graph_with_many_levels(gpu_faiss):
         assert fill >= min(M, len(members) - 1) * 0.5, (l, fill)
     flat = gpu_faiss.IndexFlat(d, 0)
     flat.add(x)
-    q = x[::151][:600]
+    q = np.ascontiguousarray(x[::151][:600])
     _, It = flat.search(q, 10)
     idx.hnsw.efSearch = 64
     rec = {}
