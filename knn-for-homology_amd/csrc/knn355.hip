@@ -170,6 +170,21 @@ __global__ void to_bf16_kernel(const float *__restrict__ src, int64_t total, __b
     }
 }
 
+// The queries of a difference-build scan (fewer than 20 of them), interleaved by pairs so that one 16-byte LDS read hands a
+// lane two consecutive k of BOTH queries of a pair as two aligned register pairs (flat_scan_kernel<..., DNQ>):
+//   out[2p    ][32 s + i] = query (2p + (i & 1)) [32 s + i / 2]        (k = 0..15 of K step s)
+//   out[2p + 1][32 s + i] = query (2p + (i & 1)) [32 s + 16 + i / 2]   (k = 16..31)
+// for p < dnq / 2; queries past the last one repeat it (their scores are never looked at).
+__global__ void diff_interleave_kernel(const float *__restrict__ xq, int64_t nq, int dp, int dnq, float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)dnq * dp) return;
+    const int row = (int)(i / dp), col = (int)(i - (int64_t)row * dp);
+    const int pr = row >> 1, half = row & 1, step = col >> 5, w = col & 31;
+    const int64_t q = min((int64_t)(2 * pr + (w & 1)), nq - 1);
+    out[i] = xq[q * dp + 32 * step + 16 * half + (w >> 1)];
+}
+
 // ---------------------------------------------------------------------------
 // workgroup-wide bitonic sort of P (power of two) u64 keys in LDS, ascending
 // ---------------------------------------------------------------------------
@@ -642,6 +657,7 @@ struct ScanParams {
     const float *yn;   // [nb] squared norms (L2 only)
     const float *xq;   // [nq][dp] queries
     const float *xn;   // [nq] squared norms (L2 only)
+    const float *xq_diff; // difference builds: [DNQ][dp] the queries interleaved by pairs (diff_interleave_kernel)
     int64_t nb, nq;
     int dp;            // multiple of 32
     int k;
@@ -924,16 +940,17 @@ __device__ __forceinline__ void sched_spread()
 // |x|^2 + |y|^2 - 2<x,y>.  Contract: ONE fp32 chain per (query, row), acc = fma(t, t, acc) with t = x[k] - y[k], k in the
 // same order as the dot product (0,4,1,5,2,6,3,7 per block of 8).  No matrix instruction computes that: the 32-query
 // tile's staging, lists, thresholds, seeding and selection are kept and the K step's MFMAs are replaced by vector
-// subtract / fma chains -- thread = row of the 256-row tile (its 32 floats of the K step in registers), one chain per
-// query, the queries' floats read from LDS as broadcasts.  Behind the K loop the scores are transposed through the staging
-// buffers into the accumulator layout the MFMA would have left (lane (i, h) = query i, registers = 32 rows), so the filter,
-// the tile-minimum seed and everything else are shared.  Two rows' chains of one query share packed fp32 instructions
-// (v_pk_add_f32 / v_pk_fma_f32).  Measured, 10 M x 1024 rows: 12.1 ms for 13-19 queries (scalar chains: 19.4; the MFMA
-// scan with the norm formula: 7.0-7.4 ms); builds for up to 12 and up to 4 queries (a single query: its HBM time).
+// subtract / fma chains -- thread = two rows of the 256-row tile (their 32 floats of the K step in registers), one chain per
+// (query, row), the queries' floats read from LDS as broadcasts.  Behind the K loop the scores are transposed through the
+// staging buffers into the accumulator layout the MFMA would have left (lane (i, h) = query i, registers = 32 rows), so the
+// filter, the tile-minimum seed and everything else are shared.  The chains of the two queries of a PAIR against one row
+// share packed fp32 instructions (v_pk_add_f32 / v_pk_fma_f32; round 4 -- round 3 packed two rows of one query: 12.2 ms per
+// 10 M x 1024 rows for 13-19 queries, bound by LDS bank conflicts; scalar chains: 19.4; the MFMA scan with the norm formula:
+// 7.0-7.4 ms); builds for up to 12 and up to 4 queries (a single query: its HBM time).
 template <int WM, int WN, int TM, int TN, bool L2, bool NTDB = false, bool SYM = false, bool BF16 = false, int DNQ = 0>
 __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 {
-    constexpr bool DIFF = DNQ > 0; // the difference build, for batches of up to DNQ queries (4, 12 or 20)
+    constexpr bool DIFF = DNQ > 0; // the difference build, for batches of up to DNQ queries (4, 8, 12, 16 or 20)
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(!DIFF || (L2 && !SYM && !BF16 && WN == 1 && TN == 1), "the difference build: one 32-query tile, squared L2");
     constexpr int DT = WM * TM * 32;        // database rows per tile
@@ -1041,8 +1058,12 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
             int rq = row_local - DT;
             rloc[n] = rq;
             int s = sp ^ ((rq >> 1) & 7);
-            int64_t q = min(q0 + rq, p.nq - 1);
-            srcp[n] = p.xq + q * p.dp + 4 * s;
+            if constexpr (DNQ > 0) { // the difference build stages the queries interleaved by pairs: DNQ rows of diff_interleave_kernel's matrix
+                srcp[n] = p.xq_diff + (int64_t)min(rq, DNQ - 1) * p.dp + 4 * s;
+            } else {
+                int64_t q = min(q0 + rq, p.nq - 1);
+                srcp[n] = p.xq + q * p.dp + 4 * s;
+            }
         }
     }
     const int swz = (li >> 1) & 7;
@@ -1095,7 +1116,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
         constexpr int DIFF_NQ = DIFF ? DNQ : 1; // (the difference build serves batches of fewer than 20 queries: one chain per query)
-        f32x2 dacc2[(DIFF_NQ + 1) / 2];        // ... as one chain per query and row; a thread holds two rows x half the queries (see compute)
+        f32x2 dacc2[(DIFF_NQ + 1) / 2];        // ... as one chain per query and row; a thread holds two rows x half the query pairs: [row][pair] (see compute)
 #pragma unroll
         for (int qi = 0; qi < (DIFF_NQ + 1) / 2; qi++) dacc2[qi] = f32x2{0.0f, 0.0f};
 
@@ -1131,40 +1152,67 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
             if constexpr (DIFF) {
 #pragma unroll
                 for (int n = 0; n < ND; n++) dma(n); // (the next K step's staging goes out first: the chains below take microseconds)
-                // thread = a PAIR of rows (2 rp, 2 rp + 1) and half of the queries: the two rows' chains of one query run in
-                // the two halves of packed fp32 instructions (v_pk_add / v_pk_fma: half the vector instructions).  A pair
-                // shares its LDS swizzle, so (y0[k], y1[k]) is one ds_read2_b32; the queries' floats are broadcast reads.
-                // k = 8t + m, 8t + 4 + m, m = 0..3: the dot product's order, for either row.
-                const int rp = (wave & 1) * 64 + lane, qh = wave >> 1;
-                const char *yrow = A + (2 * rp) * 128;
-                const int rs = rp & 7; // ((2 rp) >> 1) & 7 -- the same for 2 rp + 1
-                f32x2 y[8][4];
+                // thread = TWO rows (r0, r0 + 128) and half of the query PAIRS; the two halves of a packed fp32 instruction are
+                // the two queries of a pair: (qa[k] - y[k], qb[k] - y[k]), squared and added into the pair's two chains
+                // (v_pk_add_f32 / v_pk_fma_f32).  The queries are staged INTERLEAVED by pairs (diff_interleave_kernel: staged
+                // row 2p holds qa[k], qb[k] for k = 0..15 of the K step, row 2p + 1 for k = 16..31), so one ds_read_b128 (a
+                // broadcast: every lane reads the same address) delivers two k of both queries as two aligned register pairs,
+                // and the row's own floats come as plain ds_read_b128 fragments (consecutive lanes = consecutive rows: no bank
+                // conflict), broadcast into both halves by op_sel.  Round 3 packed two ROWS per instruction instead: their
+                // floats needed 32 ds_read2_b32 per K step that hit 8 of the 32 banks (4-way conflicts), every wave re-read
+                // every query float, and the K step was bound by the LDS (12.2 ms per 10 M rows x 19 queries).
+                //   Chains: 2 rows x NPH pairs per thread, all independent, interleaved instruction by instruction; the query
+                // fragments of the half-block after next are requested while this one is computed.  Every chain visits
+                // k = 8t + m, 8t + 4 + m (m = 0..3, t = 0..3): the dot product's order.
+                constexpr int NPH = DIFF_NQ / 4;
+                const int r0 = (wave & 1) * 64 + lane, qh = wave >> 1;
+                const int fy = (lane >> 1) & 7; // (r0 >> 1) & 7 -- the same for r0 + 128
+                f32x4 y0[8], y1[8];
 #pragma unroll
                 for (int sl = 0; sl < 8; sl++) {
-                    const float *p0 = (const float *)(yrow + ((sl ^ rs) * 16));
-#pragma unroll
-                    for (int e = 0; e < 4; e++) y[sl][e] = f32x2{p0[e], p0[e + 32]};
+                    y0[sl] = *(const f32x4 *)(A + r0 * 128 + ((sl ^ fy) * 16));
+                    y1[sl] = *(const f32x4 *)(A + (r0 + 128) * 128 + ((sl ^ fy) * 16));
                 }
+                f32x4 qv[2][NPH][2];
+                // half-block hb (8 per K step): block t = hb / 2 (8 k), its half u = hb % 2: k = 8t + 2u, 8t + 4 + 2u, 8t + 2u + 1,
+                // 8t + 4 + 2u + 1 -- 16-byte slots 4 (t & 1) + u and 4 (t & 1) + 2 + u of staged row 2p + t / 2
+                auto loadq = [&](int hb) {
+                    const int t = hb >> 1, u = hb & 1;
 #pragma unroll
-                for (int qi = 0; qi < DIFF_NQ / 2; qi++) {
-                    const int q = qh * (DIFF_NQ / 2) + qi;
-                    const char *qrow = B + q * 128;
-                    const int qs = (q >> 1) & 7;
-                    f32x2 c = dacc2[qi];
+                    for (int j = 0; j < NPH; j++) {
+                        const int pr = qh * NPH + j;
+                        const char *qrow = B + (2 * pr + (t >> 1)) * 128;
+                        const int fq = pr & 7; // ((2 pr) >> 1) & 7 -- the same for 2 pr + 1
+                        qv[hb & 1][j][0] = *(const f32x4 *)(qrow + (((4 * (t & 1) + u) ^ fq) * 16));
+                        qv[hb & 1][j][1] = *(const f32x4 *)(qrow + (((4 * (t & 1) + 2 + u) ^ fq) * 16));
+                    }
+                };
+                auto chains = [&](int hb) {
+                    const int t = hb >> 1, u = hb & 1;
 #pragma unroll
-                    for (int t = 0; t < 4; t++) {
-                        const f32x4 qa = *(const f32x4 *)(qrow + (((2 * t) ^ qs) * 16));
-                        const f32x4 qb = *(const f32x4 *)(qrow + (((2 * t + 1) ^ qs) * 16));
+                    for (int e = 0; e < 2; e++) {       // first / second k of the slots
 #pragma unroll
-                        for (int m = 0; m < 4; m++) {
-                            const f32x2 ta = f32x2{qa[m], qa[m]} - y[2 * t][m];
-                            c = __builtin_elementwise_fma(ta, ta, c);
-                            const f32x2 tb = f32x2{qb[m], qb[m]} - y[2 * t + 1][m];
-                            c = __builtin_elementwise_fma(tb, tb, c);
+                        for (int ab = 0; ab < 2; ab++) { // slot 4 (t & 1) + u (k = 8t + ..), then slot .. + 2 (k = 8t + 4 + ..)
+                            const float ya = y0[2 * t + ab][2 * u + e], yb = y1[2 * t + ab][2 * u + e];
+#pragma unroll
+                            for (int j = 0; j < NPH; j++) {
+                                const f32x4 v = qv[hb & 1][j][ab];
+                                const f32x2 qp = e == 0 ? f32x2{v[0], v[1]} : f32x2{v[2], v[3]};
+                                const f32x2 ta = qp - f32x2{ya, ya};
+                                dacc2[j] = __builtin_elementwise_fma(ta, ta, dacc2[j]);
+                                const f32x2 tb = qp - f32x2{yb, yb};
+                                dacc2[NPH + j] = __builtin_elementwise_fma(tb, tb, dacc2[NPH + j]);
+                            }
                         }
                     }
-                    dacc2[qi] = c;
-                    if ((qi & 1) == 1) __builtin_amdgcn_sched_barrier(0); // (two queries' reads in flight, not all ten)
+                };
+                loadq(0);
+                loadq(1);
+#pragma unroll
+                for (int hb = 0; hb < 8; hb++) {
+                    chains(hb);
+                    if (hb + 2 < 8) loadq(hb + 2);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 return;
             }
@@ -1276,9 +1324,16 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
             float *sT = (float *)smem; // [DIFF_NQ][DT]
             __syncthreads();           // (every wave has read its last fragments)
             {
-                const int rp = (wave & 1) * 64 + lane, qh = wave >> 1;
+                constexpr int NPH = DIFF_NQ / 4;
+                const int r0 = (wave & 1) * 64 + lane, qh = wave >> 1;
 #pragma unroll
-                for (int qi = 0; qi < DIFF_NQ / 2; qi++) *(f32x2 *)(sT + (qh * (DIFF_NQ / 2) + qi) * DT + 2 * rp) = dacc2[qi];
+                for (int j = 0; j < NPH; j++) {
+                    const int pr = qh * NPH + j; // queries 2 pr, 2 pr + 1
+                    sT[(2 * pr) * DT + r0] = dacc2[j][0];
+                    sT[(2 * pr + 1) * DT + r0] = dacc2[j][1];
+                    sT[(2 * pr) * DT + r0 + 128] = dacc2[NPH + j][0];
+                    sT[(2 * pr + 1) * DT + r0 + 128] = dacc2[NPH + j][1];
+                }
             }
             __syncthreads();
 #pragma unroll
@@ -2173,6 +2228,7 @@ struct knn_index_s {
     DevBuf ws_sym;                // work table of a symmetric all-vs-all launch
     int sym_tiles = -1, sym_run = 0; // ... which is the table for this many tiles (run length sym_run, sym_items entries)
     int64_t sym_items = 0;
+    DevBuf ws_qdiff;              // difference builds: the queries interleaved by pairs
     DevBuf ws_defer;              // tile-minimum seed: the parked first-tile scores of every workgroup
     DevBuf ws_turn;               // batch launches: one word per CU (the resident workgroups take turns in their K loops)
     int64_t sym_searches = 0;     // self-searches served by the symmetric path
@@ -2404,7 +2460,7 @@ extern "C" void knn_free(knn_handle h)
         if (h->stream) (void)hipStreamSynchronize(h->stream);
         if (!h->is_view && h->xb) (void)hipDeviceSynchronize(); // a view's stream may still be scanning these rows
         free_index_buffers(h);
-        DevBuf *bufs[] = {&h->xb16, &h->ws_q16, &h->ws_sym, &h->ws_defer, &h->ws_turn, &h->ws_flag, &h->ws_q, &h->ws_qn, &h->ws_lists, &h->ws_D, &h->ws_I, &h->ws_tmp, &h->ws_tmp2, &h->ws_D1, &h->ws_I1, &h->ws_tmp3};
+        DevBuf *bufs[] = {&h->xb16, &h->ws_q16, &h->ws_sym, &h->ws_qdiff, &h->ws_defer, &h->ws_turn, &h->ws_flag, &h->ws_q, &h->ws_qn, &h->ws_lists, &h->ws_D, &h->ws_I, &h->ws_tmp, &h->ws_tmp2, &h->ws_D1, &h->ws_I1, &h->ws_tmp3};
         for (DevBuf *b : bufs) b->release();
         for (LevelBufs &b : h->ws_level) {
             b.qlist.release();
@@ -2710,6 +2766,9 @@ struct ScanPlan {
 };
 
 
+// the difference build that serves a batch of nq < 20 queries: its width (a multiple of 4: two query pairs per thread half)
+static int diff_build_width(int64_t nq) { return nq <= 4 ? 4 : (nq <= 8 ? 8 : (nq <= 12 ? 12 : (nq <= 16 ? 16 : 20))); }
+
 template <int WM, int WN, int TM, int TN>
 static int launch_scan_cfg(const knn_index_s *h, const ScanParams &p, const ScanPlan &plan, hipStream_t s)
 {
@@ -2718,9 +2777,15 @@ static int launch_scan_cfg(const knn_index_s *h, const ScanParams &p, const Scan
     // one query tile: rows are read once, non-temporal staging loads
     if constexpr (WM == 4 && TM == 2) {
         if (plan.diff) {
-            // (a build for up to 4 queries -- a single query scans at the speed of its HBM traffic -- and one for up to 19)
-            kern = p.nq <= 4 ? flat_scan_kernel<4, 1, 2, 1, true, true, false, false, 4>
-                             : (p.nq <= 12 ? flat_scan_kernel<4, 1, 2, 1, true, true, false, false, 12> : flat_scan_kernel<4, 1, 2, 1, true, true, false, false, 20>);
+            // (builds for up to 4, 8, 12, 16 and 19 queries: the vector work of a K step grows with the build's width -- up to 4
+            // queries scan at the speed of their HBM traffic)
+            switch (diff_build_width(p.nq)) {
+            case 4: kern = flat_scan_kernel<4, 1, 2, 1, true, true, false, false, 4>; break;
+            case 8: kern = flat_scan_kernel<4, 1, 2, 1, true, true, false, false, 8>; break;
+            case 12: kern = flat_scan_kernel<4, 1, 2, 1, true, true, false, false, 12>; break;
+            case 16: kern = flat_scan_kernel<4, 1, 2, 1, true, true, false, false, 16>; break;
+            default: kern = flat_scan_kernel<4, 1, 2, 1, true, true, false, false, 20>; break;
+            }
             HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds));
             hipLaunchKernelGGL(kern, dim3(plan.grid), dim3(256), plan.lds, s, p);
             HIP_TRY(hipGetLastError());
@@ -3041,6 +3106,15 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     p.pub_m = pub_m;
     p.pair_ctr = pl.npairs ? (uint32_t *)lb.pair_ctr.p : nullptr;
     p.npairs = pl.npairs;
+    if (pl.diff) {
+        // (the build launch_scan_cfg picks: up to 4, 12 or 20 queries)
+        const int dnq = diff_build_width(nq);
+        if (h->ws_qdiff.ensure((size_t)dnq * h->dp * 4, h->done, s)) return set_err(KNN_ERR_HIP, "search: out of device memory");
+        const int64_t tot = (int64_t)dnq * h->dp;
+        hipLaunchKernelGGL(diff_interleave_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, q_dev, nq, h->dp, dnq, (float *)h->ws_qdiff.p);
+        HIP_TRY(hipGetLastError());
+        p.xq_diff = (const float *)h->ws_qdiff.p;
+    }
     if (pl.nqtiles > 1 && !h->approx16 && pl.tiles_base >= 2 && !(h->flags & 256)) { // (turn taking: batch launches with real chunks)
         if (h->ws_turn.ensure(2048 * 4, h->done, s)) return set_err(KNN_ERR_HIP, "search: out of device memory");
         HIP_TRY(hipMemsetAsync(h->ws_turn.p, 0, 2048 * 4, s));

@@ -18,7 +18,7 @@ for nb in (1_250_000, 10_000_000):
         x = torch.randn((m, 1024), generator=g, device=dev)
         _lib.check(L.knn_flat_add_dev(idx._h, x.data_ptr(), m, None))
         del x
-    for nq in (1, 8, 19):
+    for nq in (1, 4, 8, 12, 16, 19):
         q = torch.randn((nq, 1024), generator=g, device=dev)
         D = torch.empty((nq, 100), device=dev); I = torch.empty((nq, 100), device=dev, dtype=torch.int64)
         for flags in (0, 32):
