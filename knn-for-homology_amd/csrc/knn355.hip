@@ -947,17 +947,27 @@ __device__ __forceinline__ void sched_spread()
 // share packed fp32 instructions (v_pk_add_f32 / v_pk_fma_f32; round 4 -- round 3 packed two rows of one query: 12.2 ms per
 // 10 M x 1024 rows for 13-19 queries, bound by LDS bank conflicts; scalar chains: 19.4; the MFMA scan with the norm formula:
 // 7.0-7.4 ms); builds for up to 12 and up to 4 queries (a single query: its HBM time).
-template <int WM, int WN, int TM, int TN, bool L2, bool NTDB = false, bool SYM = false, bool BF16 = false, int DNQ = 0>
+// Q16 > 0: the wave's query columns are Q16 blocks of SIXTEEN (v_mfma_f32_16x16x4_f32 -- the same k-ordered fma chain, bit for
+// bit: tools/micro/mfma16.hip; lane (i, g = lane / 16) feeds k = g of each instruction: floats 8t + {0, 4, 1, 5}[g] and
+// 8t + {2, 6, 3, 7}[g] per block of 8) instead of TN blocks of 32: a 48-query tile (4 x 1 waves, 33..48 queries) and a
+// 96-query tile (2 x 2 waves, 65..96 queries) pay for 48 / 96 columns of matrix work, not 64 / 128.  One-query-tile launches
+// only (plain fp32).
+template <int WM, int WN, int TM, int TN, bool L2, bool NTDB = false, bool SYM = false, bool BF16 = false, int DNQ = 0, int Q16 = 0>
 __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 {
     constexpr bool DIFF = DNQ > 0; // the difference build, for batches of up to DNQ queries (4, 8, 12, 16 or 20)
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(!DIFF || (L2 && !SYM && !BF16 && WN == 1 && TN == 1), "the difference build: one 32-query tile, squared L2");
+    constexpr bool M16 = Q16 > 0;
+    static_assert(!M16 || (NTDB && !SYM && !BF16 && DNQ == 0 && TN == 1), "16-query blocks: plain fp32, one query tile per launch");
     constexpr int DT = WM * TM * 32;        // database rows per tile
-    constexpr int QT = WN * TN * 32;        // queries per workgroup
+    constexpr int QT = WN * (M16 ? Q16 * 16 : TN * 32); // queries per workgroup
+    constexpr int NB = M16 ? Q16 : TN;      // query blocks of a wave (of 16 / 32 queries)
+    constexpr int NS = TM * (M16 ? 8 : 16); // scores of one query block a lane holds per tile
     constexpr int ROWS = DT + QT;           // staged rows per K step
-    constexpr int NI = ROWS / 8 / 4;        // staging instructions per wave per K step
-    static_assert(ROWS % 32 == 0, "staging split");
+    constexpr int NGRP = ROWS / 8;          // staging instructions per K step (8 rows each) ...
+    constexpr int NI = (NGRP + 3) / 4;      // ... per wave; a wave short of one (304 rows: 38 over 4 waves) repeats its previous one
+    static_assert(ROWS % 8 == 0, "staging split");
     constexpr int STAGE_BYTES = ROWS * 128; // 32 floats per row
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *stage0 = smem;
@@ -969,6 +979,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // (scalar: the LDS targets of the staging instructions are then SGPR arithmetic, no v_readfirstlane per instruction)
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
+    const int lq = M16 ? (lane & 15) : li, lg = M16 ? (lane >> 4) : lh; // this lane's query of a block / its row group (accumulator layout)
 
     int qtile, chunk;
     int64_t c_lo, c_hi;
@@ -1045,6 +1056,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 #pragma unroll
     for (int n = 0; n < NI; n++) {
         int ii = wave + 4 * n;
+        if (ii >= NGRP) ii -= 4; // (the same rows once more, to the same place: harmless)
         int row_local = 8 * ii + (lane >> 3);
         int sp = lane & 7;
         lds_off[n] = ii * 1024;
@@ -1108,13 +1120,28 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
                 }
             }
         }
-        f32x16 acc[TM][TN];
+        f32x16 acc[M16 ? 1 : TM][M16 ? 1 : TN];
+        f32x4 acc16[M16 ? 2 * TM : 1][M16 ? Q16 : 1]; // 16-query blocks: [row tile of 16][query block], lane (q = lane & 15, g = lane / 16): rows 4 g + r
 #pragma unroll
-        for (int a = 0; a < TM; a++)
+        for (int a = 0; a < (M16 ? 1 : TM); a++)
 #pragma unroll
-            for (int b = 0; b < TN; b++)
+            for (int b = 0; b < (M16 ? 1 : TN); b++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
+#pragma unroll
+        for (int a = 0; a < (M16 ? 2 * TM : 1); a++)
+#pragma unroll
+            for (int b = 0; b < (M16 ? Q16 : 1); b++) acc16[a][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        // score s (0 .. NS) of query block b in this lane: its accumulator register, and its row inside the tile
+        auto accv = [&](int b, int s) -> float {
+            if constexpr (M16) return acc16[s >> 2][b][s & 3];
+            else return acc[s >> 4][b][s & 15];
+        };
+        auto rowl = [&](int s) -> int {
+            if constexpr (M16) return (wm * TM * 2 + (s >> 2)) * 16 + 4 * lg + (s & 3);
+            else return (wm * TM + (s >> 4)) * 32 + 4 * lh + (s & 3) + 8 * ((s & 15) >> 2);
+        };
+        auto qloc = [&](int b) -> int { return M16 ? (wn * Q16 + b) * 16 + lq : (wn * TN + b) * 32 + li; };
         constexpr int DIFF_NQ = DIFF ? DNQ : 1; // (the difference build serves batches of fewer than 20 queries: one chain per query)
         f32x2 dacc2[(DIFF_NQ + 1) / 2];        // ... as one chain per query and row; a thread holds two rows x half the query pairs: [row][pair] (see compute)
 #pragma unroll
@@ -1216,6 +1243,59 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
                 }
                 return;
             }
+            if constexpr (M16) {
+                // 16 x 16 x 4 tiles: a wave's 64 rows are RT = 2 TM row tiles, its queries Q16 blocks.  Lane (i = lane & 15,
+                // g = lane / 16) feeds k = g of every instruction, and the chain must visit k = 0,4,1,5 | 2,6,3,7 of each
+                // block of 8: the lane reads the 16-byte slot 2t + (g & 1) of its row (floats 8t + 4 (g & 1) ..) and hands
+                // element g / 2 to the block's first instruction, element g / 2 + 2 to its second.
+                constexpr int RT = 2 * TM;
+                const int g = lane >> 4, swz16 = ((lane & 15) >> 1) & 7;
+                const bool upper = (g >> 1) != 0;
+                f32x4 af16[2][RT], bf16[2][Q16];
+                auto frag16 = [&](int t) {
+                    const int slot = ((2 * t + (g & 1)) ^ swz16) * 16;
+#pragma unroll
+                    for (int a = 0; a < RT; a++)
+                        af16[t & 1][a] = *(const f32x4 *)(A + ((wm * RT + a) * 16 + (lane & 15)) * 128 + slot);
+#pragma unroll
+                    for (int b = 0; b < Q16; b++)
+                        bf16[t & 1][b] = *(const f32x4 *)(B + ((wn * Q16 + b) * 16 + (lane & 15)) * 128 + slot);
+                };
+                constexpr int M = 2 * RT * Q16; // MFMAs per sub-step
+                frag16(0);
+                __builtin_amdgcn_sched_group_barrier(0x100, RT + Q16, 0);
+                auto substep16 = [&](auto t_tag) {
+                    constexpr int t = decltype(t_tag)::value;
+                    if constexpr (t < 3) frag16(t + 1);
+#pragma unroll
+                    for (int half = 0; half < 2; half++) {
+                        float av[RT], bv[Q16];
+#pragma unroll
+                        for (int a = 0; a < RT; a++) av[a] = upper ? af16[t & 1][a][2 * half + 1] : af16[t & 1][a][2 * half];
+#pragma unroll
+                        for (int b = 0; b < Q16; b++) bv[b] = upper ? bf16[t & 1][b][2 * half + 1] : bf16[t & 1][b][2 * half];
+#pragma unroll
+                        for (int a = 0; a < RT; a++)
+#pragma unroll
+                            for (int b = 0; b < Q16; b++)
+                                acc16[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc16[a][b], 0, 0, 0);
+                    }
+                    constexpr int TD = 2;
+                    constexpr int n0 = t < TD ? ND * t / TD : ND, n1 = t < TD ? ND * (t + 1) / TD : ND;
+#pragma unroll
+                    for (int n = n0; n < n1; n++) dma(n);
+                    if constexpr (t < 3) __builtin_amdgcn_sched_group_barrier(0x100, RT + Q16, 0);
+                    constexpr int nd = n1 - n0, per = M / (nd + 1);
+                    static_assert(per >= 1, "more staging instructions than MFMAs in a sub-step");
+                    sched_spread<nd, per>();
+                    __builtin_amdgcn_sched_group_barrier(0x008, M - nd * per, 0);
+                };
+                substep16(std::integral_constant<int, 0>{});
+                substep16(std::integral_constant<int, 1>{});
+                substep16(std::integral_constant<int, 2>{});
+                substep16(std::integral_constant<int, 3>{});
+                return;
+            }
             // fragments of sub-step t+1 are requested before the MFMAs of sub-step t are issued,
             // so the LDS latency hides behind the matrix pipe (two register sets, fully unrolled)
             f32x4 af[2][TM], bf[2][TN];
@@ -1305,13 +1385,20 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
         for (int kt = 0; kt + 1 < KT; kt++) {
             char *cur = (kt & 1) ? stage1 : stage0;
             char *nxt = (kt & 1) ? stage0 : stage1;
-            __syncthreads(); // stage kt landed (vmcnt(0) + barrier); buffer nxt is free
+            // Stage kt has landed in LDS for EVERY wave's reads: this wave's staging instructions are waited for HERE,
+            // explicitly, then the barrier.  (Nothing else orders a ds_read behind a pending LDS-DMA: until round 4 the wait
+            // was the compiler's -- it puts a vmcnt(0) in front of LDS reads it cannot tell apart from a pending DMA's target
+            // -- and one instantiation lost it when the address arithmetic of the staging instructions changed: wrong scores
+            // from the third K step on.  Inline asm: the waitcnt pass cannot drop it.)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads(); // buffer nxt is free
             const int koff = (kt + 1) * 32;
             compute(cur, [&](int n) {
                 if (NTDB && n < DT / 32) stage_issue<true>(tsrc[n] + koff, nxt + lds_off[n]);
                 else stage_issue<false>(tsrc[n] + koff, nxt + lds_off[n]);
             }, nd_all{});
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (see above)
         __syncthreads();
         compute(((KT - 1) & 1) ? stage1 : stage0, no_dma, nd_none{});
         if constexpr (!NTDB && !BF16) {
@@ -1346,16 +1433,16 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
         KNN_TRACE(1 + 2 * tile_idx);
         if (paired && tid == 0) *s_next = next_tile; // (read by everyone behind the barrier that ends the epilogue)
 
-        // score of accumulator register r of MFMA tile (a, b) -- "smaller is better"
-        auto score_of = [&](int a, int b, int r, float xnq) -> float {
+        // score s of query block b in this lane (see accv / rowl) -- "smaller is better"
+        auto score_of = [&](int b, int s, float xnq) -> float {
             if constexpr (DIFF) {
-                return acc[a][b][r];
+                return accv(b, s);
             } else if constexpr (L2) {
-                const float ynr = s_yn[(wm * TM + a) * 32 + 4 * lh + (r & 3) + 8 * (r >> 2)];
-                const float v = __builtin_fmaf(-2.0f, acc[a][b][r], xnq + ynr);
+                const float ynr = s_yn[rowl(s)];
+                const float v = __builtin_fmaf(-2.0f, accv(b, s), xnq + ynr);
                 return v < 0.0f ? 0.0f : v;
             } else {
-                return -acc[a][b][r];
+                return -accv(b, s);
             }
         };
         // threshold filter + append of one tile's scores (getv(a, b, r, xnq): from the accumulators, or read back from
@@ -1373,22 +1460,20 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
         auto filter_tile = [&](int64_t trow0, auto &&passes, auto &&value) {
             const bool ragged = trow0 + DT > p.nb, sampled = p.skip_mask >= 0, plain_rows = p.row_mul == 1;
 #pragma unroll
-            for (int b = 0; b < TN; b++) {
-                const int ql = (wn * TN + b) * 32 + li;
+            for (int b = 0; b < NB; b++) {
+                const int ql = qloc(b);
                 const int64_t q = q0 + ql;
                 const bool qok = q < p.nq;
                 const float thr = qok ? L.threshold(ql) : -INFINITY; // (a query past the end admits nothing)
                 float xnq = 0.0f;
                 if constexpr (L2) xnq = p.xn[qok ? q : 0];
                 uint64_t *lst = L.lists + (size_t)ql * L.cap;
+                {
 #pragma unroll
-                for (int a = 0; a < TM; a++) {
-                    const int64_t rbase = trow0 + (wm * TM + a) * 32 + 4 * lh;
-#pragma unroll
-                    for (int h8 = 0; h8 < 2; h8++) {
+                    for (int s8 = 0; s8 < NS / 8; s8++) {
                         uint32_t passm = 0;
 #pragma unroll
-                        for (int r8 = 0; r8 < 8; r8++) passm |= (passes(a, b, h8 * 8 + r8, thr, xnq) ? 1u : 0u) << r8;
+                        for (int r8 = 0; r8 < 8; r8++) passm |= (passes(b, s8 * 8 + r8, thr, xnq) ? 1u : 0u) << r8;
                         if (__ballot(passm != 0u) == 0ull) continue;
 #ifdef KNN355_TRACE
                         if (p.ablate & 2) continue;
@@ -1400,9 +1485,9 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 #pragma unroll
                         for (int r8 = 0; r8 < 8; r8++) {
                             if ((passm >> r8) & 1u) {
-                                const int r = h8 * 8 + r8;
-                                const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
-                                const float vv = value(a, b, r, xnq) + 0.0f;
+                                const int sc = s8 * 8 + r8;
+                                const int64_t row = trow0 + rowl(sc);
+                                const float vv = value(b, sc, xnq) + 0.0f;
                                 const uint32_t id = p.id_base + (plain_rows ? (uint32_t)row : (uint32_t)view_row(row, p.row_mul, p.vshift));
                                 const bool gone = (ragged && row >= p.nb) || (sampled && ((int)(row >> p.vshift) & p.skip_mask) == 0);
                                 if (slot[r8] < L.cap) lst[slot[r8]] = gone ? KEY_PAD : (((uint64_t)f2ord(vv) << 32) | id);
@@ -1415,17 +1500,17 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
             }
         };
         // (squared L2: max(0, x) <= thr is x <= thr for every thr >= 0, and a threshold is a score or +inf)
-        auto passes_acc = [&](int a, int b, int r, float thr, float xnq) -> bool {
+        auto passes_acc = [&](int b, int sc, float thr, float xnq) -> bool {
             if constexpr (DIFF) {
-                return acc[a][b][r] <= thr;
+                return accv(b, sc) <= thr;
             } else if constexpr (L2) {
-                const float ynr = s_yn[(wm * TM + a) * 32 + 4 * lh + (r & 3) + 8 * (r >> 2)];
-                return __builtin_fmaf(-2.0f, acc[a][b][r], xnq + ynr) <= thr;
+                const float ynr = s_yn[rowl(sc)];
+                return __builtin_fmaf(-2.0f, accv(b, sc), xnq + ynr) <= thr;
             } else {
-                return -acc[a][b][r] <= thr;
+                return -accv(b, sc) <= thr;
             }
         };
-        constexpr int NV4 = TM * TN * 4; // 16-byte pieces of a lane's scores of one tile
+        constexpr int NV4 = NB * NS / 4; // 16-byte pieces of a lane's scores of one tile
         bool deferred = false;
         if constexpr (CAN_PUB) {
             if (pub_on && tile_idx < p.pub_rounds) {
@@ -1437,44 +1522,44 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
                 // 4 accumulator registers) and filtered behind the second tile, when the bound has long been there.
                 float4 *park = (float4 *)p.defer + (size_t)blockIdx.x * NV4 * 256 + tid;
 #pragma unroll
-                for (int b = 0; b < TN; b++) {
-                    const int ql = (wn * TN + b) * 32 + li;
+                for (int b = 0; b < NB; b++) {
+                    const int ql = qloc(b);
                     const int64_t q = q0 + ql;
                     float xnq = 0.0f;
                     if constexpr (L2) xnq = p.xn[q < p.nq ? q : 0];
                     uint64_t best = KEY_PAD;
 #pragma unroll
-                    for (int a = 0; a < TM; a++) {
-                        const int64_t rbase = row0 + (wm * TM + a) * 32 + 4 * lh;
-                        float vs[16];
+                    for (int s4 = 0; s4 < NS / 4; s4++) {
+                        float vs[4];
 #pragma unroll
-                        for (int r = 0; r < 16; r++) {
-                            const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
-                            const float v = score_of(a, b, r, xnq) + 0.0f;
-                            vs[r] = v;
+                        for (int e = 0; e < 4; e++) {
+                            const int64_t row = row0 + rowl(4 * s4 + e);
+                            const float v = score_of(b, 4 * s4 + e, xnq) + 0.0f;
+                            vs[e] = v;
                             // (a key that is published must be one the filter would append: a real row of this chunk, finite)
                             if (v < INFINITY && row < p.nb && !(p.skip_mask >= 0 && ((int)(row >> p.vshift) & p.skip_mask) == 0)) {
                                 const uint64_t key = ((uint64_t)f2ord(v) << 32) | (p.id_base + (uint32_t)view_row(row, p.row_mul, p.vshift));
                                 best = key < best ? key : best;
                             }
                         }
-                        if (tile_idx == 0) {
-#pragma unroll
-                            for (int j = 0; j < 4; j++)
-                                park[(size_t)((b * TM + a) * 4 + j) * 256] = make_float4(vs[4 * j], vs[4 * j + 1], vs[4 * j + 2], vs[4 * j + 3]);
-                        }
+                        if (tile_idx == 0) park[(size_t)(b * (NS / 4) + s4) * 256] = make_float4(vs[0], vs[1], vs[2], vs[3]);
                     }
-                    const uint32_t ohi = (uint32_t)__shfl_xor((int)(uint32_t)(best >> 32), 32);
-                    const uint32_t olo = (uint32_t)__shfl_xor((int)(uint32_t)best, 32);
-                    const uint64_t other = ((uint64_t)ohi << 32) | olo;
-                    best = other < best ? other : best;
+                    // the other lanes that hold scores of this query: the other lane half (32-query blocks), the three other
+                    // lane quarters (16-query blocks)
+#pragma unroll
+                    for (int off = M16 ? 16 : 32; off < 64; off <<= 1) {
+                        const uint32_t ohi = (uint32_t)__shfl_xor((int)(uint32_t)(best >> 32), off);
+                        const uint32_t olo = (uint32_t)__shfl_xor((int)(uint32_t)best, off);
+                        const uint64_t other = ((uint64_t)ohi << 32) | olo;
+                        best = other < best ? other : best;
+                    }
                     if (p.pub_m > 1) {
                         // every wave publishes the best key of ITS rows (WM keys of WM different rows per workgroup and query):
                         // enough publications for a k beyond the number of workgroups
-                        if (lh == 0 && q < p.nq)
+                        if (lg == 0 && q < p.nq)
                             __hip_atomic_store(&p.pub[(size_t)q * p.pub_n + ((size_t)tile_idx * p.nchunks + (paired ? (int)blockIdx.x : chunk)) * WM + wm], best,
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    } else if (lh == 0 && q < p.nq) {
+                    } else if (lg == 0 && q < p.nq) {
                         atomicMin((unsigned long long *)&s_pub[ql], (unsigned long long)best);
                     }
                 }
@@ -1511,9 +1596,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
         if (p.ablate & 4) { // all MFMA results of this wave have landed before the "K loop ended" stamp is taken
             float sink = 0.0f;
 #pragma unroll
-            for (int a = 0; a < TM; a++)
-#pragma unroll
-                for (int b = 0; b < TN; b++) sink += acc[a][b][15];
+            for (int b = 0; b < NB; b++) sink += accv(b, NS - 1) + accv(b, NS / 2 - 1);
             if (sink == 12345.678f) KNN_TRACE(61);
             KNN_TRACE(1 + 2 * tile_idx);
         }
@@ -1529,11 +1612,11 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
                 float4 pv[NV4];
 #pragma unroll
                 for (int j = 0; j < NV4; j++) pv[j] = park[(size_t)j * 256];
-                auto parked = [&](int a, int b, int r, float) -> float {
-                    const float4 w = pv[(b * TM + a) * 4 + (r >> 2)];
-                    return (r & 3) == 0 ? w.x : ((r & 3) == 1 ? w.y : ((r & 3) == 2 ? w.z : w.w));
+                auto parked = [&](int b, int sc, float) -> float {
+                    const float4 w = pv[b * (NS / 4) + (sc >> 2)];
+                    return (sc & 3) == 0 ? w.x : ((sc & 3) == 1 ? w.y : ((sc & 3) == 2 ? w.z : w.w));
                 };
-                filter_tile(first_row0, [&](int a, int b, int r, float thr, float) -> bool { return parked(a, b, r, 0.0f) <= thr; }, parked);
+                filter_tile(first_row0, [&](int b, int sc, float thr, float) -> bool { return parked(b, sc, 0.0f) <= thr; }, parked);
             }
         }
         if constexpr (SYM) {
@@ -2803,19 +2886,41 @@ static int launch_scan_cfg(const knn_index_s *h, const ScanParams &p, const Scan
     return 0;
 }
 
+// the builds on 16-query blocks (48 queries: 4 x 1 waves, 96: 2 x 2 waves; Q16 blocks per wave): one query tile per launch
+template <int WM, int WN, int TM, int Q16>
+static int launch_scan16(const knn_index_s *h, const ScanParams &p, const ScanPlan &plan, hipStream_t s)
+{
+    if (p.nqtiles != 1 || h->approx16) return set_err(KNN_ERR_INVALID, "scan: the 16-query-block builds serve one query tile of plain fp32 rows");
+    void (*kern)(ScanParams) = h->metric == KNN_METRIC_L2 ? flat_scan_kernel<WM, WN, TM, 1, true, true, false, false, 0, Q16>
+                                                          : flat_scan_kernel<WM, WN, TM, 1, false, true, false, false, 0, Q16>;
+    HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds));
+    hipLaunchKernelGGL(kern, dim3(plan.grid), dim3(256), plan.lds, s, p);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 static void make_plan(const knn_index_s *h, int64_t nb, int64_t nq, int k, bool seeded, ScanPlan &pl, bool allow_pairs = false)
 {
     int qt = h->force_qt;
-    if (qt != 32 && qt != 64 && qt != 128) qt = nq <= 32 ? 32 : (nq <= 64 ? 64 : 128);
+    // (48 and 96: the 16-query-block builds, one query tile per launch only -- a forced one is honoured if it holds the batch)
+    if ((qt == 48 || qt == 96) && (nq > qt || h->approx16)) qt = 0;
+    if (qt != 32 && qt != 48 && qt != 64 && qt != 96 && qt != 128) {
+        qt = nq <= 32 ? 32 : (nq <= 64 ? 64 : 128);
+        if (!h->approx16 && !(h->flags & 131072)) { // (flags & 131072: without the 16-query-block builds)
+            if (nq > 32 && nq <= 48) qt = 48;
+            else if (nq > 64 && nq <= 96) qt = 96;
+        }
+    }
     // FAISS's squared L2 for fewer than 20 queries: the sum of squared differences (flags & 32: the norm formula throughout).
     // FAISS decides on the batch its caller handed over, so a piece of a larger batch (the last block of 16384 queries, the
     // remainder behind the full query tiles) keeps the formula of the whole.
     const bool small_batch = (h->batch_nq ? h->batch_nq : nq) < 20 && nq < 20;
     if (h->metric == KNN_METRIC_L2 && small_batch && !h->approx16 && !(h->flags & 32)) qt = 32; // (the difference build exists for the 32-query tile only)
     pl.qt = qt;
-    pl.dt = qt == 32 ? 256 : 128;
+    pl.dt = (qt == 32 || qt == 48) ? 256 : 128;
     pl.diff = h->metric == KNN_METRIC_L2 && small_batch && qt == 32 && !h->approx16 && !(h->flags & 32);
-    pl.name = pl.diff ? "flat_scan_q32_d256_l2diff" : (qt == 128 ? "flat_scan_q128_d128" : (qt == 64 ? "flat_scan_q64_d128" : "flat_scan_q32_d256"));
+    pl.name = pl.diff ? "flat_scan_q32_d256_l2diff"
+                      : (qt == 128 ? "flat_scan_q128_d128" : (qt == 96 ? "flat_scan_q96_d128" : (qt == 64 ? "flat_scan_q64_d128" : (qt == 48 ? "flat_scan_q48_d256" : "flat_scan_q32_d256"))));
     pl.nqtiles = (int)((nq + qt - 1) / qt);
     pl.cap = next_pow2_host(2 * k + pl.dt);
     if (pl.cap < 512) pl.cap = 512;
@@ -3002,7 +3107,7 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
         // 64-query one, all of different rows, no reduction across the waves.  The k-th smallest of P such keys sits near the
         // -P ln(1 - k / P) / (P x rows per wave) quantile (k = 1000, P = 2048: 1372 of 131 k sampled rows; 2 M rows x 32
         // queries: 2.30 ms unseeded -- every workgroup warming up its own 1000 best -- against 1.45 at k = 100).
-        const int wm = pl.qt == 32 ? 4 : 2;
+        const int wm = (pl.qt == 32 || pl.qt == 48) ? 4 : 2;
         for (int r = 2; r >= 1; r--) { // (one round if it gives enough publications; 4096 keys are selected by probing them in memory)
             const int64_t P = (int64_t)r * wm * pl.nchunks;
             if (P <= 4096 && P >= (int64_t)k + k / 4 + 32 && r < pl.tiles_base) {
@@ -3152,6 +3257,8 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
         HIP_TRY(hipEventRecord(h->ev0, s));
     }
     if (pl.qt == 128) rc = launch_scan_cfg<2, 2, 2, 2>(h, p, pl, s);
+    else if (pl.qt == 96) rc = launch_scan16<2, 2, 2, 3>(h, p, pl, s);
+    else if (pl.qt == 48) rc = launch_scan16<4, 1, 2, 3>(h, p, pl, s);
     else if (pl.qt == 64) rc = launch_scan_cfg<2, 2, 2, 1>(h, p, pl, s);
     else rc = launch_scan_cfg<4, 1, 2, 1>(h, p, pl, s);
     if (rc) return rc;
@@ -3257,12 +3364,15 @@ static int search_keys_impl(knn_index_s *h, const float *q_dev, int64_t nq, int 
             continue;
         }
         const int64_t full = m / 128 * 128, r = m - full;
-        if (!split || m <= 64 || r == 0 || r > 96 || (r > 64 && full)) { // (65..96 behind full tiles: the two narrow passes cost what the padded tile does)
+        // (round 4: 33..48 and 65..96 queries have builds of their own width -- 16-query blocks, make_plan -- so a remainder of
+        // up to 96 queries is one piece: 10 M rows x 80 queries: 18.7 ms as 64 + 16, ~16 as one 96-query pass)
+        const bool q96 = !h->approx16 && !(h->flags & 131072);
+        if (!split || m <= 64 || r == 0 || r > 96 || (r > 64 && full && !q96) || (!full && q96)) { // (without the 96-query build: 65..96 behind full tiles cost two narrow passes what the padded tile does)
             pieces.push_back({q0, m});
             continue;
         }
         if (full) pieces.push_back({q0, full});
-        if (r > 64) {
+        if (r > 64 && !q96) {
             pieces.push_back({q0 + full, 64});
             pieces.push_back({q0 + full + 64, r - 64});
         } else {
@@ -3936,12 +4046,12 @@ extern "C" int knn_flat_reserve(knn_handle h, int64_t nrows)
 extern "C" int knn_set_tuning(knn_handle h, int32_t query_tile, int32_t nchunks, int32_t flags)
 {
     if (!h) return set_err(KNN_ERR_INVALID, "null handle");
-    if (query_tile != 0 && query_tile != 32 && query_tile != 64 && query_tile != 128)
-        return set_err(KNN_ERR_INVALID, "set_tuning: query_tile must be 0, 32, 64 or 128");
+    if (query_tile != 0 && query_tile != 32 && query_tile != 48 && query_tile != 64 && query_tile != 96 && query_tile != 128)
+        return set_err(KNN_ERR_INVALID, "set_tuning: query_tile must be 0, 32, 48, 64, 96 or 128");
     std::lock_guard<std::mutex> lk(h->mu);
     h->force_qt = query_tile;
     h->force_chunks = nchunks;
-    h->flags = flags & ~(3 << 12);
+    h->flags = flags & ~(3 << 12); // (bit 17 = 131072: plans without the 16-query-block builds, see make_plan)
     h->pub_rounds_force = (flags >> 12) & 3; // bits 12-13: publication rounds of the tile-minimum seed (0: the host's choice)
     return 0;
 }

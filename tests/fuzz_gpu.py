@@ -27,13 +27,13 @@ def run(ncases=200, seed=1, budget_s=None):
         ran = case + 1
         d = int(rng.choice([1, 3, 8, 31, 32, 33, 64, 100, 128, 257, 512, 1024]))
         nb = int(rng.choice([1, 2, 7, 63, 64, 65, 255, 256, 257, 1000, 4097, 8193, 20000, 70001]))
-        nq = int(rng.choice([1, 2, 31, 32, 33, 64, 65, 127, 128, 129, 300, 1000]))
+        nq = int(rng.choice([1, 2, 31, 32, 33, 40, 48, 49, 64, 65, 80, 96, 97, 127, 128, 129, 170, 300, 1000]))
         if nb * nq * d > 3e10:
             nq = max(1, int(3e10 / (nb * d)))
         k = int(rng.choice([1, 2, 10, 11, 64, 100, 101, 301, 512, 1000, 1537, 2048]))
         metric = int(rng.integers(0, 2))
         flags = int(rng.choice([0, 0, 0, 8, 16, 128, 128]))
-        qt = int(rng.choice([0, 0, 0, 32, 64, 128]))
+        qt = int(rng.choice([0, 0, 0, 0, 32, 48, 64, 96, 128]))
         nch = int(rng.choice([0, 0, 0, 1, 3, 17]))
         kind = int(rng.integers(0, 6))
         if kind == 0:

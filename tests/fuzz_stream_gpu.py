@@ -29,12 +29,12 @@ def run(ncases=40, seed=1, budget_s=None):
         ran = case + 1
         d = int(rng.choice([8, 16, 31, 32, 48, 64]))
         nb = int(rng.choice([131_072, 140_000, 200_001, 262_144, 300_000, 400_003, 524_288, 530_000, 600_001, 777_777, 1_048_577, 1_300_000]))
-        nq = int(rng.choice([1, 2, 7, 31, 32, 33, 64]))
+        nq = int(rng.choice([1, 2, 7, 31, 32, 33, 41, 48, 64]))
         k = int(rng.choice([1, 2, 10, 64, 100, 101, 200, 256, 481, 600, 1000, 1536, 1537, 1800, 2048]))
         metric = int(rng.integers(0, 2))
         flags = int(rng.choice([0, 0, 0, 2, 4, 2048, 2048 | 4, 8, 1 << 12, 2 << 12]))
         if rng.integers(0, 5) == 0:  # a batch searched in pieces (the remainder behind the full 128-query tiles on its own)
-            nq = int(rng.choice([65, 96, 129, 150, 161, 193, 257]))
+            nq = int(rng.choice([65, 81, 96, 129, 150, 161, 170, 193, 224, 257]))
             k = min(k, 256)
             d = min(d, 32)
             flags = int(rng.choice([0, 0, 16384, 2048]))

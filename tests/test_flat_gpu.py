@@ -148,6 +148,63 @@ def test_random_vs_oracle(gpu_faiss, oracle, nq, nb, d, k, qt, nch, metric):
     _assert_same(D, I, Do, Io)
 
 
+# ---- the builds on 16-query blocks (v_mfma_f32_16x16x4_f32): 33..48 queries -> 48-query tile, 65..96 -> 96-query tile --------
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("nq,nb,d,k,nch", [
+    (33, 5000, 1024, 100, 0), (48, 5000, 1024, 100, 3), (41, 700, 37, 11, 0), (40, 6000, 256, 1536, 0), (45, 9001, 100, 2048, 0),
+    (65, 5000, 1024, 100, 0), (96, 5000, 1024, 100, 5), (80, 2049, 100, 13, 0), (90, 6000, 128, 1025, 0), (70, 300, 64, 301, 1),
+    (36, 70001, 64, 10, 0),     # >= 64 tiles of 256 rows: paired walk + tile-minimum seed in the 48-query build
+    (47, 140000, 32, 600, 0),   # ... with one published key per wave (k beyond the workgroup count)
+    (77, 70001, 64, 10, 0),     # 32 k .. 262 k rows, k <= 200: two self-seeding pieces (64 + 13) stay ahead of one unseeded 96-query launch
+    (77, 70001, 64, 300, 0),    # ... a larger k: the one 96-query launch under the statistical seed
+])
+def test_sixteen_query_block_builds_vs_oracle(gpu_faiss, oracle, nq, nb, d, k, nch, metric):
+    """a query tile costs its whole width -- 33 queries paid for 64, 65 for 128.  The 48- and 96-query
+    tiles are built from 16 x 16 x 4 MFMAs (the same k-ordered fma chain: every bit as before).  The plan picks them by itself;
+    flags 131072 switches them off: the same bits either way."""
+    rng = np.random.default_rng(nq * 7919 + nb + d + k)
+    xb = rng.standard_normal((nb, d), dtype=np.float32)
+    xb[nb // 2: nb // 2 + 5] = xb[:5]  # exact duplicates: ties -> lower id
+    xq = rng.standard_normal((nq, d), dtype=np.float32)
+    xq[:3] = xb[:3]
+    idx = gpu_faiss.IndexFlat(d, metric)
+    idx.set_tuning(0, nch, 0)
+    idx.add(xb)
+    D, I = idx.search(xq, k)
+    in_pieces = nq > 64 and 32768 <= nb < 262144 and k <= 200 and nch == 0
+    assert idx.last_scan()["query_tile"] == (32 if in_pieces else (48 if nq <= 48 else 96)), idx.last_scan()
+    Do, Io = oracle.flat_search(xb, xq, k, metric)
+    _assert_same(D, I, Do, Io)
+    idx.set_tuning(0, nch, 131072)
+    D2, I2 = idx.search(xq, k)
+    assert idx.last_scan()["query_tile"] in (32, 64, 128)
+    _assert_same(D2, I2, Do, Io)
+    # forced on a smaller batch (a tile holds any batch that fits it)
+    idx.set_tuning(48 if nq <= 48 else 96, nch, 0)
+    D3, I3 = idx.search(xq[:nq - 7], k)
+    _assert_same(D3, I3, Do[:nq - 7], Io[:nq - 7])
+
+
+def test_remainders_behind_full_query_tiles_use_their_own_width(gpu_faiss, oracle):
+    """128 k + r queries on a database that is streamed from HBM: the remainder r is searched with the narrowest build that
+    holds it (32 / 48 / 64 / 96 queries); the pieces return the bits of one launch (flags 16384)."""
+    rng = np.random.default_rng(5)
+    nb, d, k = 300_000, 32, 20
+    xb = rng.standard_normal((nb, d), dtype=np.float32)
+    idx = gpu_faiss.IndexFlat(d, 0)
+    idx.add(xb)
+    for nq, tile in ((128 + 40, 48), (256 + 90, 96), (70, 96), (44, 48)):
+        xq = rng.standard_normal((nq, d), dtype=np.float32)
+        idx.set_tuning(0, 0, 0)
+        D, I = idx.search(xq, k)
+        assert idx.last_scan()["query_tile"] == tile, (nq, idx.last_scan())
+        idx.set_tuning(0, 0, 16384)
+        D1, I1 = idx.search(xq, k)
+        _assert_same(D, I, D1, I1)
+        Do, Io = oracle.flat_search(xb, xq[-8:], k, 0)
+        _assert_same(D[-8:], I[-8:], Do, Io)
+
+
 def test_query_batching_over_16384(gpu_faiss, oracle):
     """Host searches run in batches of 16384 queries; results must not depend on it."""
     rng = np.random.default_rng(41)
@@ -773,7 +830,7 @@ def test_tile_minimum_seed_with_adversarial_order(gpu_faiss, oracle):
 
 
 @pytest.mark.parametrize("metric,nb,d,nq,k,keys", [(0, 620_000, 32, 32, 1000, 4), (1, 620_000, 32, 7, 600, 4), (0, 560_000, 24, 32, 1536, 4),
-                                                   (1, 620_000, 32, 48, 600, 2), (0, 620_000, 32, 64, 700, 2), (1, 600_000, 40, 21, 481, 4)])
+                                                   (1, 620_000, 32, 48, 600, 4), (0, 620_000, 32, 64, 700, 2), (1, 600_000, 40, 21, 481, 4)])
 def test_tile_minimum_seed_with_one_key_per_wave_for_large_k(gpu_faiss, oracle, metric, nb, d, nq, k, keys):
     """k beyond the number of workgroups (two rounds of 512 publications carry k <= 480): every wave publishes the best
     key of its own rows of the first tile (4 per workgroup and query with the 32-query tile, 2 with the 64-query one).
@@ -838,7 +895,9 @@ def test_short_streaming_launches_pair_and_seed_themselves(gpu_faiss, oracle, me
     idx = gpu_faiss.IndexFlat(d, metric)
     idx.add(xb)
     D, I = idx.search(xq, k)
-    assert idx.last_seed()["stride"] < 0 and idx.last_scan()["grid"] == 512, (idx.last_seed(), idx.last_scan())
+    tile = 256 if nq <= 48 else 128  # (the 32- and 48-query builds walk 256-row tiles)
+    pairs = min(256, -(-nb // tile) // 2)
+    assert idx.last_seed()["stride"] < 0 and idx.last_scan()["grid"] == 2 * pairs, (idx.last_seed(), idx.last_scan())
     Do, Io = oracle.flat_search(xb, xq, k, metric)
     _assert_same(D, I, Do, Io)
     D1, I1 = idx.search(xq, k)
@@ -864,10 +923,12 @@ def test_batches_of_65_to_128_queries_on_a_mid_sized_database_go_as_two_pieces(g
         xq[0] = xb[3]
         idx.set_tuning(0, 0, 0)
         D, I = idx.search(xq, k)
-        assert idx.last_scan()["kernel"] == ("flat_scan_q128_d128" if nq > 128 else ("flat_scan_q64_d128" if nq != 65 else "flat_scan_q32_d256")), (nq, idx.last_scan())
+        rest = nq - 64  # (the second piece: the narrowest build that holds it)
+        second = "flat_scan_q32_d256" if rest <= 32 else ("flat_scan_q48_d256" if rest <= 48 else "flat_scan_q64_d128")
+        assert idx.last_scan()["kernel"] == ("flat_scan_q128_d128" if nq > 128 else ("flat_scan_q64_d128" if nq <= 64 else second)), (nq, idx.last_scan())
         idx.set_tuning(0, 0, 16384)
         D1, I1 = idx.search(xq, k)
-        assert idx.last_scan()["kernel"] == ("flat_scan_q128_d128" if nq > 64 else "flat_scan_q64_d128")
+        assert idx.last_scan()["kernel"] == ("flat_scan_q128_d128" if nq > 96 else ("flat_scan_q96_d128" if nq > 64 else "flat_scan_q64_d128"))
         _assert_same(D, I, D1, I1)
         _assert_same(D, I, *oracle.flat_search(xb, xq, k, metric))
 
@@ -1066,7 +1127,7 @@ def test_l2_formula_follows_the_whole_batch_not_its_pieces(gpu_faiss, oracle):
 @pytest.mark.parametrize("metric", [0, 1])
 def test_remainder_behind_the_full_query_tiles_is_searched_on_its_own(gpu_faiss, oracle, metric):
     """On a database that is streamed from HBM the queries behind the last full 128-query tile are searched with the
-    narrowest build that holds them (<= 32: streaming build, <= 64: 64-query build; a batch of 65..96: both) instead of a padded
+    narrowest build that holds them (<= 32: streaming build, <= 48 / 64 / 96: the 48- / 64- / 96-query builds) instead of a padded
     128-query tile.  Same bits as one launch (flags 16384) and as the oracle, whatever the split."""
     rng = np.random.default_rng(129 + metric)
     nb, d, k = 300_000, 32, 20
@@ -1081,13 +1142,14 @@ def test_remainder_behind_the_full_query_tiles_is_searched_on_its_own(gpu_faiss,
         D, I = idx.search(xq, k)
         last = idx.last_scan()["kernel"]
         r = nq % 128
-        if nq > 64 and (0 < r <= 64 or nq < 128 and r <= 96):
-            assert last == ("flat_scan_q64_d128" if 32 < r <= 64 else "flat_scan_q32_d256"), (nq, last)
-        else:
-            assert last == ("flat_scan_q128_d128" if nq > 64 else "flat_scan_q64_d128"), (nq, last)
+
+        def build(m):  # the narrowest build that holds m queries
+            return ("flat_scan_q32_d256" if m <= 32 else ("flat_scan_q48_d256" if m <= 48 else ("flat_scan_q64_d128" if m <= 64 else
+                    ("flat_scan_q96_d128" if m <= 96 else "flat_scan_q128_d128"))))
+        assert last == (build(r) if 0 < r <= 96 else "flat_scan_q128_d128"), (nq, last)
         idx.set_tuning(0, 0, 16384)
         D1, I1 = idx.search(xq, k)
-        assert idx.last_scan()["kernel"] == ("flat_scan_q128_d128" if nq > 64 else "flat_scan_q64_d128")
+        assert idx.last_scan()["kernel"] == (build(nq) if nq <= 128 else "flat_scan_q128_d128")
         _assert_same(D, I, D1, I1)
         _assert_same(D, I, *oracle.flat_search(xb, xq, k, metric))
 
