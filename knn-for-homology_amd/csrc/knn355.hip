@@ -1270,10 +1270,18 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 #pragma unroll
                     for (int half = 0; half < 2; half++) {
                         float av[RT], bv[Q16];
+                        // (one v_cndmask per operand.  The empty asm keeps the two candidates opaque: left alone, the compiler
+                        // folds a fragment's two selects into ONE extraction with a four-way dynamic index and spends three
+                        // v_cndmask on each)
+                        auto pick = [&](const f32x4 &v) -> float {
+                            float lo = v[2 * half], hi = v[2 * half + 1];
+                            asm("" : "+v"(lo), "+v"(hi));
+                            return upper ? hi : lo;
+                        };
 #pragma unroll
-                        for (int a = 0; a < RT; a++) av[a] = upper ? af16[t & 1][a][2 * half + 1] : af16[t & 1][a][2 * half];
+                        for (int a = 0; a < RT; a++) av[a] = pick(af16[t & 1][a]);
 #pragma unroll
-                        for (int b = 0; b < Q16; b++) bv[b] = upper ? bf16[t & 1][b][2 * half + 1] : bf16[t & 1][b][2 * half];
+                        for (int b = 0; b < Q16; b++) bv[b] = pick(bf16[t & 1][b]);
 #pragma unroll
                         for (int a = 0; a < RT; a++)
 #pragma unroll
