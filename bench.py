@@ -311,7 +311,7 @@ def run(args):
         out["scan_ms_per_rank"] = {"min": min(ok) if ok else None, "max": max(ok) if ok else None, "all": scan_ms_ranks,
                                    "note": "mean HIP-event duration of each rank's scan launches (with two searches in flight a launch's "
                                            "events span the other lane's work too)"}
-    sweep_ref = shard_sweep_reference(nb_local, in_flight)
+    sweep_ref = None if rehearse else shard_sweep_reference(nb_local, in_flight)  # (a rehearsal's times mean nothing: N ranks share one GPU over gloo)
     if sweep_ref is not None:
         # what ONE GPU needs for a shard of this size with no collective at all (builder-run sweep, committed): the part of a
         # multi-GPU step that is not the scan shows up as efficiency < 1
