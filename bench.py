@@ -859,9 +859,31 @@ def hnsw_config(dev, L, _lib, faiss):
         ts.append(time.perf_counter() - t0)
     t = float(np.median(ts))
     recall = float(np.mean([len(np.intersect1d(a[a >= 0], b)) for a, b in zip(Ih, It)])) / k
-    return {"workload": "BASELINE configs[4]: 200000x1024 clustered (2000 centres + 0.35 noise), IP, HNSW M=32 efConstruction=40 efSearch=256, k=100",
-            "build_s": build_s, "queries_per_s": nq / t, "recall_at_100_vs_flat": recall, "nq": nq,
-            "flat_queries_per_s_same_queries": nq / t_flat, "note": "host numpy in/out for both (IndexHNSWFlat.search / IndexFlat.search)"}
+    out = {"workload": "BASELINE configs[4]: 200000x1024 clustered (2000 centres + 0.35 noise), IP, HNSW M=32 efConstruction=40 efSearch=256, k=100",
+           "build_s": build_s, "queries_per_s": nq / t, "recall_at_100_vs_flat": recall, "nq": nq,
+           "flat_queries_per_s_same_queries": nq / t_flat, "note": "host numpy in/out for both (IndexHNSWFlat.search / IndexFlat.search)"}
+    del idx
+    # the reference's own shape (pfam/proteins_search.py:30-31,49): M = 42, efSearch = 256, k = 1000 (FAISS walks with ef = max(efSearch, k));
+    # its consumers read the first 300 hits (pfam/proteins.py:41,246): recall at that depth beside recall@1000
+    kr = 1000
+    ref = faiss.IndexHNSWFlat(d, 42, faiss.METRIC_INNER_PRODUCT)
+    t0 = time.perf_counter()
+    ref.add(xh)
+    build_ref = time.perf_counter() - t0
+    ref.hnsw.efSearch = 256
+    ref.search(qh[:256], kr)
+    t0 = time.perf_counter()
+    Dr, Ir = ref.search(qh, kr)
+    t_ref = time.perf_counter() - t0
+    _, Itr = flat.search(qh, kr)
+
+    def rec(depth):
+        return float(np.mean([len(np.intersect1d(a[a >= 0], b)) for a, b in zip(Ir[:, :depth], Itr[:, :depth])])) / depth
+    out["reference_shape"] = {"workload": "pfam/proteins_search.py hnsw mode: M=42, IP, efSearch=256, k=1000, same rows",
+                              "build_s": build_ref, "queries_per_s": nq / t_ref, "nq": nq,
+                              "recall_at_300_vs_flat": rec(300), "recall_at_1000_vs_flat": rec(1000), "recall_at_100_vs_flat": rec(100),
+                              "note": "recall@N: the first N returned hits against the exact first N (the reference's consumers slice [:, :300])"}
+    return out
 
 
 if __name__ == "__main__":

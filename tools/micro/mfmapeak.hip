@@ -91,7 +91,8 @@ int main(int argc, char** argv)
                 mhz = acc / grid;
             }
         }
-        double flops = (double)grid * 4 * iters * 16.0 * (32 * 32 * 2 * 2);
+        // (per loop iteration a wave issues 16 MFMAs of the 32x32x2 shape or 64 of the 16x16x4 shape: 65536 / 131072 flop)
+        double flops = (double)grid * 4 * iters * (shape == 32 ? 16.0 * (32 * 32 * 2 * 2) : 64.0 * (16 * 16 * 4 * 2));
         printf("shape %s  %s operands: %.3f ms  %.1f TFLOP/s  in-kernel clock %.0f MHz\n", shape == 32 ? "32x32x2" : "16x16x4",
                random ? "random  " : "constant", best, flops / best / 1e9, mhz);
     }

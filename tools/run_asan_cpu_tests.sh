@@ -4,7 +4,7 @@
 # gcc's sanitizers, then runs the CPU test suite against them.  The log goes to profiles/rNN_asan_cpu_tests.log.
 # usage: tools/run_asan_cpu_tests.sh [round-tag]
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd "$ROOT"
 make -C knn-for-homology_amd/csrc asan
