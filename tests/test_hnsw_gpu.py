@@ -468,7 +468,7 @@ def test_reference_shape_at_pfam_size(gpu_faiss):
     # the depth the reference's consumers read: pfam/proteins.py:41,246 slice [:, :300] of the saved hits
     r300 = _recall(I[sample][:, :300], It[:, :300])
     print(f"recall@1000 {r:.4f}, recall@300 of the first three hundred {r300:.4f}, recall@100 of the first hundred {r100:.4f}")
-    assert r300 >= 0.85, r300
+    assert r300 >= 0.93, r300
     # (ef = k on 2000 clusters of 100 rows: the ranks past the query's own cluster are decided by score differences of
     # 1e-2 among 2000 equidistant clusters; the sequential oracle loses the same ranks at the sizes it can build -- see
     # the test above and tests/probe_hnsw_reference_shape.py: 40 k rows of this structure, oracle 0.902, device 0.911)
