@@ -30,6 +30,12 @@ def short(name):
     if "flat_scan_kernel<" in name:
         targs = name[name.index("flat_scan_kernel<") + len("flat_scan_kernel<"):].split(">")[0].split(", ")
         tile = {"4, 1, 2, 1": "flat_scan_q32_d256", "2, 2, 2, 1": "flat_scan_q64_d128", "2, 2, 2, 2": "flat_scan_q128_d128"}[", ".join(targs[:4])]
+        if len(targs) > 9 and targs[9] != "0":  # builds on 16-query blocks: 4 x 1 waves -> 48 queries, 2 x 2 waves -> 96
+            tile = "flat_scan_q48_d256" if targs[0] == "4" else "flat_scan_q96_d128"
+        if len(targs) > 8 and targs[8] != "0":  # difference builds (squared L2, fewer than 20 queries)
+            tile = f"flat_scan_q32_d256_l2diff{targs[8]}"
+        if len(targs) > 7 and targs[7] == "true":  # bf16 operands (HNSW's coarse entry scan)
+            tile += "_bf16"
         return tile + ("_l2" if targs[4] == "true" else "_ip") + ("_sym" if len(targs) > 6 and targs[6] == "true" else "")
     return name.split("(")[0].replace("void ", "")[:60]
 
