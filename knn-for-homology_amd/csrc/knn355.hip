@@ -49,6 +49,9 @@ typedef const __attribute__((address_space(1))) f32x4 *gptr4; // explicit global
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define KEY_PAD 0xFFFFFFFFFFFFFFFFull
+#ifndef KNN355_STREAM_DMA_FIRST
+#define KNN355_STREAM_DMA_FIRST 1 // streaming launches issue a K step's staging instructions in front of its first MFMA (flat_scan_kernel)
+#endif
 
 // ---------------------------------------------------------------------------
 // device helpers
@@ -955,7 +958,7 @@ __device__ __forceinline__ void sched_spread()
 template <int WM, int WN, int TM, int TN, bool L2, bool NTDB = false, bool SYM = false, bool BF16 = false, int DNQ = 0, int Q16 = 0>
 __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 {
-    constexpr bool DIFF = DNQ > 0; // the difference build, for batches of up to DNQ queries (4, 8, 12, 16 or 20)
+    constexpr bool DIFF = DNQ > 0; // the difference build, for batches of up to DNQ queries (8, 12, 16 or 20)
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(!DIFF || (L2 && !SYM && !BF16 && WN == 1 && TN == 1), "the difference build: one 32-query tile, squared L2");
     constexpr bool M16 = Q16 > 0;
@@ -1289,7 +1292,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
                                 acc16[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc16[a][b], 0, 0, 0);
                     }
                     constexpr int TD = 2;
-                    constexpr int n0 = t < TD ? ND * t / TD : ND, n1 = t < TD ? ND * (t + 1) / TD : ND;
+                    constexpr int n0 = t < TD ? ND * t / TD : ND, n1 = t < TD ? ND * (t + 1) / TD : ND; // (spread over the first half: see the 32 x 32 x 2 path)
 #pragma unroll
                     for (int n = n0; n < n1; n++) dma(n);
                     if constexpr (t < 3) __builtin_amdgcn_sched_group_barrier(0x100, RT + Q16, 0);
@@ -1341,8 +1344,20 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
                 // staging instructions [n0, n1) of the next K step belong to this sub-step; all of
                 // them go out in the first TD sub-steps of the K step so that the rest covers
                 // their latency before the next barrier's vmcnt(0)
-                constexpr int TD = NTDB ? 2 : 3; // (streaming launches wait for HBM: early; batch launches hit L2: spread wider, +1 %)
-                constexpr int n0 = t < TD ? ND * t / TD : ND, n1 = t < TD ? ND * (t + 1) / TD : ND;
+                constexpr int TD = NTDB ? 2 : 3; // (batch launches hit L2: spread wide, +1 %)
+                // Streaming launches (one query tile, rows straight from HBM): EVERY staging instruction of the next K step goes
+                // out in front of this K step's first MFMA -- the longest lead the double buffer allows.  (Rounds 2-3 spread them
+                // over the first half of the K step so that their issue cost hid behind MFMAs: 1.2-3 % slower once the epilogue and
+                // the walk were what they are now -- 10 M x 32 queries 7.39 -> 7.30 ms, 1.25 M rows 0.972 -> 0.945 ms, same box.)
+                // (the 32- and 64-query builds only: the 128-query one-tile launch is bound by the matrix pipe and lost 2 % with it,
+                // the builds on 16-query blocks 0.5 %)
+                constexpr bool FIRST = NTDB && QT <= 64 && KNN355_STREAM_DMA_FIRST;
+                if constexpr (FIRST && t == 0) {
+#pragma unroll
+                    for (int n = 0; n < ND; n++) dma(n);
+                    __builtin_amdgcn_sched_group_barrier(0x010, ND, 0);
+                }
+                constexpr int n0 = FIRST ? ND : (t < TD ? ND * t / TD : ND), n1 = FIRST ? ND : (t < TD ? ND * (t + 1) / TD : ND);
 #pragma unroll
                 for (int n = n0; n < n1; n++) dma(n);
                 // pin the order: LDS reads of t+1, then the MFMAs of t with the staging
@@ -2858,7 +2873,9 @@ struct ScanPlan {
 
 
 // the difference build that serves a batch of nq < 20 queries: its width (a multiple of 4: two query pairs per thread half)
-static int diff_build_width(int64_t nq) { return nq <= 4 ? 4 : (nq <= 8 ? 8 : (nq <= 12 ? 12 : (nq <= 16 ? 16 : 20))); }
+// (no 4-query build: with two chains per thread it is bound by their dependent latency -- 6.9 ms per 10 M rows where the 8-query
+// build, four chains per thread, reads at the HBM rate: 6.25 ms)
+static int diff_build_width(int64_t nq) { return nq <= 8 ? 8 : (nq <= 12 ? 12 : (nq <= 16 ? 16 : 20)); }
 
 template <int WM, int WN, int TM, int TN>
 static int launch_scan_cfg(const knn_index_s *h, const ScanParams &p, const ScanPlan &plan, hipStream_t s)
@@ -2868,10 +2885,9 @@ static int launch_scan_cfg(const knn_index_s *h, const ScanParams &p, const Scan
     // one query tile: rows are read once, non-temporal staging loads
     if constexpr (WM == 4 && TM == 2) {
         if (plan.diff) {
-            // (builds for up to 4, 8, 12, 16 and 19 queries: the vector work of a K step grows with the build's width -- up to 4
+            // (builds for up to 8, 12, 16 and 19 queries: the vector work of a K step grows with the build's width -- up to 8
             // queries scan at the speed of their HBM traffic)
             switch (diff_build_width(p.nq)) {
-            case 4: kern = flat_scan_kernel<4, 1, 2, 1, true, true, false, false, 4>; break;
             case 8: kern = flat_scan_kernel<4, 1, 2, 1, true, true, false, false, 8>; break;
             case 12: kern = flat_scan_kernel<4, 1, 2, 1, true, true, false, false, 12>; break;
             case 16: kern = flat_scan_kernel<4, 1, 2, 1, true, true, false, false, 16>; break;
