@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (gpurun): the round's committed measurements in one call -- box read rate, shard sweep,
 # SURVEY 8(d) input sets, the small-batch L2 kernel, and the rocprofv3 passes of the default bench.
 # usage: tools/run_round_measurements.sh <round-tag>
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/$TAG
 ./tools/micro/readbw 5 40 > gpurun_out/$TAG/readbw.txt 2>&1
