@@ -26,6 +26,8 @@ Also on the same JSON line (N=1 only, outside the timed region):
                 2 M-row sample: `value` = the fastest faithful variant -- oracle/cpu_scan.c
                 (OpenMP + AVX-512, NUMA first-touch), FAISS's blocked-sgemm algorithm on numpy's
                 BLAS, the real faiss when importable -- next to the host's own DRAM read rate
+  shard_unit    a 1.25 M-row shard (the per-GPU unit of the 8-GPU run, strong or weak) on this GPU: step time, one and two
+                searches in flight
   sweep         the same index at nq = 1, 8, 32, 1024, 10 000 queries per search
   host_buffers  one step through the host-pointer entry (H2D of the queries + D2H of D/I)
   batch         BASELINE configs[1]: CATH20-sized all-vs-all (14433 x 1024, L2, k = 300 + self)
@@ -370,6 +372,7 @@ def run(args):
     if hnsw_rep is not None:
         out["hnsw_replicas"] = hnsw_rep
     if world == 1 and not args.no_extras:
+        out["shard_unit"] = shard_unit_step(dev, L, _lib, faiss, d, k, q)
         out["sweep"] = nq_sweep(index, dev, L, _lib, d, k, nb_local)
         out["host_buffers"] = host_buffer_step(index, q.cpu().numpy(), k)
     if world == 1 and not args.no_cpu and cpu_rows is not None:
@@ -470,6 +473,47 @@ def query_sharded_all_vs_all(dev, L, _lib, faiss, rank, world, dist):
     del idx, x, D, I
     torch.cuda.empty_cache()
     return out
+
+
+def shard_unit_step(dev, L, _lib, faiss, d, k, q):
+    """The per-GPU unit of the 8-GPU run on ONE GPU, measured in this run: 1.25 M x 1024 rows (10 M / 8 = the strong-scaling
+    shard = the weak-scaling unit of SURVEY 8(d)), the bench's 32 queries, one search in flight and two.  No collective: what is
+    left of a multi-GPU step once the all-gather is taken out (tools/shard_sweep.py sweeps N = 1, 2, 4, 8)."""
+    from knn_for_homology_amd.sharded import ShardedFlatIndex
+    nb = 1_250_000
+    idx = ShardedFlatIndex(d, faiss.METRIC_INNER_PRODUCT, rank=0, world=1, row_offset=0)
+    idx.reserve(nb)
+    g = torch.Generator(device=dev)
+    g.manual_seed(29)
+    for i0 in range(0, nb, 250_000):
+        x = torch.randn((250_000, d), generator=g, device=dev)
+        _lib.check(L.knn_normalize_l2_dev(x.data_ptr(), 250_000, d, None))
+        idx.add_dev(x)
+        del x
+    rec = {"rows": nb, "queries_per_step": int(q.shape[0]), "k": k}
+    for lanes in (1, 2):
+        best = None
+        for _rep in range(3):
+            for _ in range(5):
+                if lanes == 1:
+                    idx.backend._turn = 0
+                idx.submit(q, k)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(40):
+                if lanes == 1:
+                    idx.backend._turn = 0
+                pend = idx.submit(q, k)
+            torch.cuda.synchronize()
+            t = (time.perf_counter() - t0) / 40
+            best = t if best is None else min(best, t)
+        pend.result()
+        rec[f"ms_in_flight_{lanes}"] = 1e3 * best
+        rec[f"hbm_frac_in_flight_{lanes}"] = nb * d * 4 / best / 1e9 / HBM_PEAK_GBS
+    rec["note"] = "best of 3 x 40 steps each; whole step (scan + selection), rows x d x 4 bytes per step against 8 TB/s"
+    del idx
+    torch.cuda.empty_cache()
+    return rec
 
 
 def nq_sweep(index, dev, L, _lib, d, k, nb):
