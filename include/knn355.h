@@ -168,10 +168,13 @@ int knn_sharded_search_dev(knn_handle h, knn_comm c, const float *q_dev, int64_t
  * rows of all nodes above level 0 picks the entry points (knn_hnsw_set_entry; 0 = FAISS's
  * greedy descent through the upper levels, on the host), one wave per query walks level 0
  * with a beam of ef = max(efSearch, k) entries, and the beam's rows are re-scored with the
- * flat search's arithmetic: every returned distance carries the flat index's bits.
+ * flat search's arithmetic: every returned distance carries the flat index's bits (squared L2:
+ * the sum of squared differences at every batch size, as FAISS's HNSW distance computer --
+ * the bits a flat search of fewer than 20 queries returns).
  * Construction is batch-synchronous and deterministic: level-0 candidates from the same
- * device pipeline, only the nodes above level 0 (1 in M) are linked by host walkers whose
- * distances come from the GPU (knn_gather_distances is that offload as a public entry).
+ * device pipeline, the candidates of the levels above from exact scans of the coarse index
+ * (points whose highest levels that scan cannot fill fall back to host walkers with GPU
+ * distances; knn_gather_distances is that offload as a public entry).
  * Results use the flat index's layout; slots the walk could not fill hold id -1. */
 typedef struct knn_hnsw_s *knn_hnsw_handle;
 int knn_hnsw_create(int32_t d, int32_t M, int32_t metric, knn_hnsw_handle *out);
@@ -283,13 +286,14 @@ int32_t knn_scan_times(knn_handle h, float *out_ms, int32_t max_n);
  * stride of the sample searched first, or -r (tile-minimum seed: no sample pass, every chunk of the
  * scan publishes r keys per query -- the best key of each of its first r tiles (r = 1, 2) or, for a k beyond
  * what that supports, the best key of each wave's rows of the first tile (r = 4 with the 32-query tile, 2 with the
- * 64-query tile) -- and the k-th smallest published key is the bound); stat_rank = 0 (the sample's k-th score, a proven bound)
+ * 64-query tile; 4 with the 48-query tile) -- and the k-th smallest published key is the bound); stat_rank = 0 (the sample's k-th score, a proven bound)
  * or j (statistical seed: the sample's j-th score, result verified); stat_redo = searches
  * repeated so far because a statistical threshold failed its verification; sample_rows =
  * rows scanned by the sample pass (the main scan kernel skips them) */
 int knn_last_seed_info(knn_handle h, int32_t *seed_stride, int32_t *stat_rank, int64_t *stat_redo,
                        int64_t *sample_rows);
-/* force a scan configuration: query_tile in {0(auto),32,64,128}; nchunks 0=auto (a forced count also turns the paired
+/* force a scan configuration: query_tile in {0(auto),32,48,64,96,128} (48 and 96: the builds on 16-query MFMA blocks, one
+ * query tile per launch -- honoured when the batch fits the tile, ignored otherwise); nchunks 0=auto (a forced count also turns the paired
  * walk off); flags, all off by default:
  *      2  no shared pool of tiles in a paired (one-query-tile) launch
  *      4  never pair the workgroups of a one-query-tile launch: static chunks instead
@@ -307,6 +311,7 @@ int knn_last_seed_info(knn_handle h, int32_t *seed_stride, int32_t *stat_rank, i
  *   bits 12-13  publication rounds of the tile-minimum seed (0 = the library's choice)
  *  16384  never search the remainder behind the full 128-query tiles as a piece of its own (large databases: 129 queries
  *         are one 128-query launch and one streaming launch instead of two 128-query passes)
+ * 131072  plans without the 48- and 96-query tiles (33..48 queries then pay for a 64-query tile, 65..96 for 128 or two pieces)
  * Only 32 changes what a search returns (the other formula's rounding); every other combination returns the same bits. */
 int knn_set_tuning(knn_handle h, int32_t query_tile, int32_t nchunks, int32_t flags);
 
