@@ -191,6 +191,8 @@ class PendingSearch:
 
     def check(self):
         if self._status is not None:
+            if self._event is not None and self._status.is_cuda:  # (not yet ordered behind the lane's stream by result())
+                torch.cuda.current_stream(self._status.device).wait_event(self._event)
             st = self._status.cpu()
             self._status = None
             failed = [int(r) for r in st.tolist() if r >= 0]
