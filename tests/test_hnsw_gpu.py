@@ -205,6 +205,40 @@ def test_graph_invariants_and_determinism(gpu_faiss):
     assert np.array_equal(b.graph()[2], nbrs)
 
 
+@pytest.mark.parametrize("metric,M,d,n,pieces", [(0, 16, 64, 60_000, 1), (1, 8, 96, 40_000, 3), (0, 42, 256, 30_000, 2)])
+def test_device_links_build_the_host_links_graph(gpu_faiss, monkeypatch, metric, M, d, n, pieces):
+    """Construction keeps level 0 on the device since round 4 (candidates, forward selection, forward links, reverse requests
+    sorted by (node, v, from), appended or pruned: hnsw.inc::hnsw_level0_links_device); KNN355_HNSW_HOST_LINKS=1 is the
+    host bookkeeping of rounds 1-3.  Same arithmetic, same request order, same members per pruning group: the two graphs
+    are IDENTICAL -- every list of every level -- and so are the search results.  (M = 8: small lists, almost every reverse
+    request prunes; several add calls: the device's lists outlive a call and the host copy is brought up to date in between
+    only when something reads it.)"""
+    x = _clustered(n, d, max(40, n // 300), 31 + M)
+    cuts = [n * i // pieces for i in range(pieces + 1)]
+
+    def build():
+        idx = gpu_faiss.IndexHNSWFlat(d, M, metric)
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            idx.add(x[a:b])
+        return idx
+
+    monkeypatch.setenv("KNN355_HNSW_HOST_LINKS", "1")
+    host = build()
+    monkeypatch.delenv("KNN355_HNSW_HOST_LINKS")
+    dev = build()
+    q = np.ascontiguousarray(x[::97][:300])
+    Dd, Id = dev.search(q, 10)      # (searched BEFORE the graph is exported: the device's lists as they are)
+    gh, gd = host.graph(), dev.graph()
+    assert np.array_equal(gh[0], gd[0]) and np.array_equal(gh[1], gd[1])
+    diff = np.flatnonzero(gh[2] != gd[2])
+    assert diff.size == 0, f"{diff.size} of {gh[2].size} slots differ, first at {diff[:5]}"
+    Dh, Ih = host.search(q, 10)
+    assert np.array_equal(Ih, Id) and np.array_equal(Dh.view(np.uint32), Dd.view(np.uint32))
+    # and the graph that went through the export is still the one the device searches
+    Dd2, Id2 = dev.search(q, 10)
+    assert np.array_equal(Id2, Id)
+
+
 def test_upper_levels_are_linked_on_a_graph_with_many_levels(gpu_faiss):
     """construction candidates of the levels >= 2 come from one top-2048 scan of the coarse index filtered
     by level; once the coarse index outgrows 2048 rows the highest levels' nodes are too rare in that scan (here: M = 4,
