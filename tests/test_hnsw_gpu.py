@@ -205,8 +205,9 @@ def test_graph_invariants_and_determinism(gpu_faiss):
     assert np.array_equal(b.graph()[2], nbrs)
 
 
-@pytest.mark.parametrize("metric,M,d,n,pieces", [(0, 16, 64, 60_000, 1), (1, 8, 96, 40_000, 3), (0, 42, 256, 30_000, 2)])
-def test_device_links_build_the_host_links_graph(gpu_faiss, monkeypatch, metric, M, d, n, pieces):
+@pytest.mark.parametrize("metric,M,d,n,pieces,efc", [(0, 16, 64, 60_000, 1, 40), (1, 8, 96, 40_000, 3, 40), (0, 42, 256, 30_000, 2, 40),
+                                                     (1, 24, 64, 30_000, 1, 150)])
+def test_device_links_build_the_host_links_graph(gpu_faiss, monkeypatch, metric, M, d, n, pieces, efc):
     """Construction keeps level 0 on the device since round 4 (candidates, forward selection, forward links, reverse requests
     sorted by (node, v, from), appended or pruned: hnsw.inc::hnsw_level0_links_device); KNN355_HNSW_HOST_LINKS=1 is the
     host bookkeeping of rounds 1-3.  Same arithmetic, same request order, same members per pruning group: the two graphs
@@ -218,6 +219,7 @@ def test_device_links_build_the_host_links_graph(gpu_faiss, monkeypatch, metric,
 
     def build():
         idx = gpu_faiss.IndexHNSWFlat(d, M, metric)
+        idx.hnsw.efConstruction = efc  # (150: more candidates than a selection group holds -- the closest 127 take part)
         for a, b in zip(cuts[:-1], cuts[1:]):
             idx.add(x[a:b])
         return idx
