@@ -163,8 +163,9 @@ int knn_sharded_search_dev(knn_handle h, knn_comm c, const float *q_dev, int64_t
 
 /* ---- faiss.IndexHNSWFlat(d, M, metric) ------------------------------------
  * pfam/proteins_search.py:27-31 (M = 42, inner product, hnsw.efSearch = 256),
- * .train (no-op) / .add :35-37, .search(x, 1000) :49.  The graph lives on the host with a
- * device mirror of its level-0 lists.  A search runs on the device: an exact scan of the
+ * .train (no-op) / .add :35-37, .search(x, 1000) :49.  The levels above 0 live on the host;
+ * the level-0 lists live on the device (the host copy is brought up to date when the graph is
+ * exported or walked on the host).  A search runs on the device: an exact scan of the
  * rows of all nodes above level 0 picks the entry points (knn_hnsw_set_entry; 0 = FAISS's
  * greedy descent through the upper levels, on the host), one wave per query walks level 0
  * with a beam of ef = max(efSearch, k) entries, and the beam's rows are re-scored with the
@@ -172,7 +173,9 @@ int knn_sharded_search_dev(knn_handle h, knn_comm c, const float *q_dev, int64_t
  * the sum of squared differences at every batch size, as FAISS's HNSW distance computer --
  * the bits a flat search of fewer than 20 queries returns).
  * Construction is batch-synchronous and deterministic: level-0 candidates from the same
- * device pipeline, the candidates of the levels above from exact scans of the coarse index
+ * device pipeline and -- since round 4 -- level-0 selection, links, reverse links and pruning
+ * on the device as well (the host path's graph, bit for bit; KNN355_HNSW_HOST_LINKS=1 is that
+ * path), the candidates of the levels above from exact scans of the coarse index
  * (points whose highest levels that scan cannot fill fall back to host walkers with GPU
  * distances; knn_gather_distances is that offload as a public entry).
  * Results use the flat index's layout; slots the walk could not fill hold id -1. */
