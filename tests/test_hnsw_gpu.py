@@ -215,6 +215,10 @@ def test_device_links_build_the_host_links_graph(gpu_faiss, monkeypatch, metric,
     request prunes; several add calls: the device's lists outlive a call and the host copy is brought up to date in between
     only when something reads it.)"""
     x = _clustered(n, d, max(40, n // 300), 31 + M)
+    # exact duplicates inside one insertion batch and across batches: two points then ask the same node for a reverse link
+    # at the same distance, and the order of the requests (node, v, from) decides who is appended first / pruned
+    x[n - 3000:n - 2000] = x[n - 2000:n - 1000]
+    x[n // 2:n // 2 + 500] = x[:500]
     cuts = [n * i // pieces for i in range(pieces + 1)]
 
     def build():
