@@ -2334,6 +2334,8 @@ struct knn_index_s {
     DevBuf ws_sym;                // work table of a symmetric all-vs-all launch
     int sym_tiles = -1, sym_run = 0; // ... which is the table for this many tiles (run length sym_run, sym_items entries)
     int64_t sym_items = 0;
+    int sym_groups = 1;           // ... in this many groups of query tiles, one launch each (results streamed to the host group by group)
+    std::vector<int64_t> sym_gstart; // [sym_groups + 1] first entry of each group
     DevBuf ws_qdiff;              // difference builds: the queries interleaved by pairs
     DevBuf ws_defer;              // tile-minimum seed: the parked first-tile scores of every workgroup
     DevBuf ws_turn;               // batch launches: one word per CU (the resident workgroups take turns in their K loops)
@@ -3569,7 +3571,13 @@ static bool self_search_symmetric_eligible(const knn_index_s *h, int k, int *j_o
     return true;
 }
 
-static int self_search_symmetric(knn_index_s *h, int k, float *D_dev, int64_t *I_dev, hipStream_t s)
+// D_host / I_host / d2h given and the result large: the query tiles are served in SYM_GROUPS launches of consecutive tiles, each
+// followed by the final selection of ITS rows -- a row's candidates are complete once every query tile up to its own has been
+// served (tile (I, J), J >= I, scores rows I against J and J against I) -- and by their download on the copy stream d2h, which
+// then overlaps the launches of the later groups (Pfam-sized k = 1000: 2.4 GB of results, 0.15 s behind a 0.38 s search).
+// Returns 2 then (the caller waits for d2h and checks the verification flag), 1 when the results are in D_dev / I_dev only.
+static int self_search_symmetric(knn_index_s *h, int k, float *D_dev, int64_t *I_dev, hipStream_t s, float *D_host = nullptr,
+                                 int64_t *I_host = nullptr, hipStream_t d2h = nullptr)
 {
     const int64_t n = h->ntotal;
     int j = 0, qcap = 0;
@@ -3598,7 +3606,10 @@ static int self_search_symmetric(knn_index_s *h, int k, float *D_dev, int64_t *I
     //    stays on the device between searches (uploading it between the sample pass and the main launch cost a host
     //    round trip -- 35 us of idle GPU -- per search).
     const int64_t slots = 2 * (int64_t)std::max(1, h->num_cus);
-    if (h->sym_tiles != T || !h->ws_sym.p) {
+    constexpr int SYM_GROUPS = 8;
+    const bool stream_out = D_host && I_host && d2h && (size_t)n * k * 12 >= ((size_t)256 << 20) && T >= 16 * SYM_GROUPS;
+    const int groups = stream_out ? SYM_GROUPS : 1;
+    if (h->sym_tiles != T || h->sym_groups != groups || !h->ws_sym.p) {
         int best_tp = 16;
         int64_t best_cost = INT64_MAX;
         for (int tp = dev_knob("KNN355_SYM_MIN_TP", 1); tp <= 96; tp++) {
@@ -3609,15 +3620,21 @@ static int self_search_symmetric(knn_index_s *h, int k, float *D_dev, int64_t *I
             if (cost < best_cost || (cost == best_cost && tp > best_tp)) { best_cost = cost; best_tp = tp; }
         }
         std::vector<SymItem> items;
-        for (int I = 0; I < T; I++)
-            for (int j0 = I; j0 < T; j0 += best_tp) items.push_back({I, j0, std::min(best_tp, T - j0)});
-        // long runs first: the short tails of every query tile fill the last round
-        std::stable_sort(items.begin(), items.end(), [](const SymItem &a, const SymItem &b) { return a.jcount > b.jcount; });
+        h->sym_gstart.assign(1, 0);
+        for (int g = 0; g < groups; g++) { // (query tiles [T g / groups, T (g + 1) / groups): equal shares of the RESULT; the first group is the longest)
+            const size_t at = items.size();
+            for (int I = (int)((int64_t)T * g / groups); I < (int)((int64_t)T * (g + 1) / groups); I++)
+                for (int j0 = I; j0 < T; j0 += best_tp) items.push_back({I, j0, std::min(best_tp, T - j0)});
+            // long runs first: the short tails of every query tile fill the last round
+            std::stable_sort(items.begin() + at, items.end(), [](const SymItem &a, const SymItem &b) { return a.jcount > b.jcount; });
+            h->sym_gstart.push_back((int64_t)items.size());
+        }
         h->sym_tiles = -1;
         if (h->ws_sym.ensure(items.size() * sizeof(SymItem), h->done, s)) return set_err(KNN_ERR_HIP, "search_self: out of device memory");
         HIP_TRY(hipMemcpyAsync(h->ws_sym.p, items.data(), items.size() * sizeof(SymItem), hipMemcpyHostToDevice, s));
         HIP_TRY(hipStreamSynchronize(s)); // (the table is a local vector)
         h->sym_tiles = T;
+        h->sym_groups = groups;
         h->sym_run = best_tp;
         h->sym_items = (int64_t)items.size();
     }
@@ -3668,27 +3685,50 @@ static int self_search_symmetric(knn_index_s *h, int k, float *D_dev, int64_t *I
     p.ablate = getenv("KNN355_ABLATE") ? atoi(getenv("KNN355_ABLATE")) : 0;
     g_trace_grid = (int)std::min<size_t>(nitems, (size_t)max_wgs);
 #endif
-    for (size_t i0 = 0; i0 < nitems; i0 += (size_t)max_wgs) {
-        const size_t cnt = std::min<size_t>((size_t)max_wgs, nitems - i0);
-        p.sym_items = (const SymItem *)h->ws_sym.p + i0;
-        hipLaunchKernelGGL(kern, dim3((unsigned)cnt), dim3(256), lds, s, p);
-        HIP_TRY(hipGetLastError());
+    // 2 + 3. the launches, each followed by the final selection of the rows it completes (verified against the sample's bound)
+    hipEvent_t gev[SYM_GROUPS] = {};
+    for (int g = 0; g < groups; g++) {
+        const size_t g0 = (size_t)h->sym_gstart[(size_t)g], g1 = (size_t)h->sym_gstart[(size_t)g + 1];
+        for (size_t i0 = g0; i0 < g1; i0 += (size_t)max_wgs) {
+            const size_t cnt = std::min<size_t>((size_t)max_wgs, g1 - i0);
+            p.sym_items = (const SymItem *)h->ws_sym.p + i0;
+            hipLaunchKernelGGL(kern, dim3((unsigned)cnt), dim3(256), lds, s, p);
+            HIP_TRY(hipGetLastError());
+        }
+        if (g == groups - 1) HIP_TRY(hipEventRecord(h->ev1, s));
+        const int64_t r0 = std::min<int64_t>(n, (int64_t)T * g / groups * 128), r1 = std::min<int64_t>(n, (int64_t)T * (g + 1) / groups * 128);
+        SelectParams sp = {};
+        sp.in = qlist + (size_t)r0 * qcap; sp.in_stride = qcap; sp.cnt = qcnt + r0; sp.cap = qcap;
+        sp.n_expect = (int)std::min<double>((double)qcap, expect);
+        sp.nq = r1 - r0; sp.k = k; sp.metric = h->metric;
+        sp.D = D_dev + (size_t)r0 * k; sp.I = I_dev + (size_t)r0 * k;
+        sp.qthr = qthr + r0; sp.fail = (int *)h->ws_flag.p;
+        rc = launch_select(sp, s, &h->ws_tmp);
+        if (rc) return rc;
+        if (stream_out) {
+            HIP_TRY(hipEventCreateWithFlags(&gev[g], hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(gev[g], s));
+        }
     }
-    HIP_TRY(hipEventRecord(h->ev1, s));
     h->last_kernel = "flat_scan_q128_d128_sym"; h->last_qt = 128; h->last_dt = 128; h->last_chunks = best_tp; h->last_grid = (int)nitems;
     h->last_seed_stride = st; h->last_seed_stat = j; h->last_sample_rows = S;
-    // 3. final selection of all n queries, verified against the sample's bound
-    SelectParams sp = {};
-    sp.in = qlist; sp.in_stride = qcap; sp.cnt = qcnt; sp.cap = qcap;
-    sp.n_expect = (int)std::min<double>((double)qcap, expect);
-    sp.nq = n; sp.k = k; sp.metric = h->metric;
-    sp.D = D_dev; sp.I = I_dev;
-    sp.qthr = qthr; sp.fail = (int *)h->ws_flag.p;
-    rc = launch_select(sp, s, &h->ws_tmp);
-    if (rc) return rc;
     if (h->done) (void)hipEventRecord(h->done, s); // (everything this search enqueued on the handle's buffers: see DevBuf::ensure)
     h->sym_searches++;
-    return 1;
+    if (!stream_out) return 1;
+    // the downloads, group by group behind their selections (everything above is enqueued: a copy into pageable memory may
+    // block this thread as long as it likes)
+    hipError_t e = hipSuccess;
+    for (int g = 0; g < groups; g++) {
+        const int64_t r0 = std::min<int64_t>(n, (int64_t)T * g / groups * 128), r1 = std::min<int64_t>(n, (int64_t)T * (g + 1) / groups * 128);
+        if (e == hipSuccess) e = hipStreamWaitEvent(d2h, gev[g], 0);
+        if (e == hipSuccess && r1 > r0) e = hipMemcpyAsync(D_host + (size_t)r0 * k, D_dev + (size_t)r0 * k, (size_t)(r1 - r0) * k * 4, hipMemcpyDeviceToHost, d2h);
+        if (e == hipSuccess && r1 > r0) e = hipMemcpyAsync(I_host + (size_t)r0 * k, I_dev + (size_t)r0 * k, (size_t)(r1 - r0) * k * 8, hipMemcpyDeviceToHost, d2h);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(d2h);
+    for (int g = 0; g < groups; g++)
+        if (gev[g]) (void)hipEventDestroy(gev[g]);
+    if (e != hipSuccess) return set_err(KNN_ERR_HIP, hipGetErrorString(e));
+    return 2;
 }
 
 // Copy streams of the pipelined host search: one set per device for the whole process, created on
@@ -3882,9 +3922,38 @@ extern "C" int knn_flat_search_self(knn_handle h, int64_t row0, int64_t nrows, i
         HIP_TRY(hipSetDevice(h->device));
         if (h->ws_D.ensure((size_t)nrows * k * 4) || h->ws_I.ensure((size_t)nrows * k * 8)) return set_err(KNN_ERR_HIP, "search_self: out of device memory");
         h->last_ms = -1.f;
-        rc = self_search_symmetric(h, (int)k, (float *)h->ws_D.p, (int64_t *)h->ws_I.p, h->stream);
+        // (a large result leaves in pieces while the later query tiles are still being served: the copy stream of the device,
+        // if no other host search of this process is using it)
+        CopyPipes &cp = g_pipes[h->device & 63];
+        std::unique_lock<std::mutex> pipes(cp.mu, std::defer_lock);
+        hipStream_t d2h = nullptr;
+        static const bool stream_off = getenv("KNN355_SELF_STREAM") && atoi(getenv("KNN355_SELF_STREAM")) == 0; // (A/B: the result in one piece behind the search)
+        if (!stream_off && (size_t)nrows * k * 12 >= ((size_t)256 << 20) && pipes.try_lock()) {
+            if (!cp.h2d) {
+                HIP_TRY(hipStreamCreateWithFlags(&cp.h2d, hipStreamNonBlocking));
+                HIP_TRY(hipStreamCreateWithFlags(&cp.d2h, hipStreamNonBlocking));
+                for (int i = 0; i < 2; i++) {
+                    HIP_TRY(hipEventCreateWithFlags(&cp.ev_query[i], hipEventDisableTiming));
+                    HIP_TRY(hipEventCreateWithFlags(&cp.ev_batch[i], hipEventDisableTiming));
+                }
+            }
+            d2h = cp.d2h;
+        }
+        rc = self_search_symmetric(h, (int)k, (float *)h->ws_D.p, (int64_t *)h->ws_I.p, h->stream, D_host, I_host, d2h);
+        if (pipes.owns_lock()) pipes.unlock();
         if (rc < 0) return rc;
-        if (rc == 1) {
+        if (rc == 2) { // (the rows went out behind their groups' selections)
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            bool failed = false;
+            rc = search_failed(h, &failed);
+            if (rc) return rc;
+            if ((size_t)nrows * k * 12 > ((size_t)1 << 30)) { // (gigabytes of result staging are not kept with the handle)
+                h->ws_D.release();
+                h->ws_I.release();
+            }
+            if (!failed) return 0;
+            // a threshold estimate was too tight or a candidate array overflowed: the plain path repeats the search
+        } else if (rc == 1) {
             HIP_TRY(hipStreamSynchronize(h->stream));
             bool failed = false;
             rc = search_failed(h, &failed);
