@@ -172,7 +172,9 @@ int knn_sharded_search_dev(knn_handle h, knn_comm c, const float *q_dev, int64_t
  * flat search's arithmetic: every returned distance carries the flat index's bits (squared L2:
  * the sum of squared differences at every batch size, as FAISS's HNSW distance computer --
  * the bits a flat search of fewer than 20 queries returns).
- * Construction is batch-synchronous and deterministic: level-0 candidates from the same
+ * Construction is batch-synchronous and deterministic; the rows of an add call are linked in a
+ * shuffled order (FAISS shuffles too: rows grouped by family must not be inserted blind to their
+ * own neighbours).  Level-0 candidates from the same
  * device pipeline and -- since round 4 -- level-0 selection, links, reverse links and pruning
  * on the device as well (the host path's graph, bit for bit; KNN355_HNSW_HOST_LINKS=1 is that
  * path), the candidates of the levels above from exact scans of the coarse index
@@ -184,7 +186,7 @@ int knn_hnsw_create(int32_t d, int32_t M, int32_t metric, knn_hnsw_handle *out);
 /* index.hnsw.efSearch / index.hnsw.efConstruction (values <= 0 leave the setting alone) */
 int knn_hnsw_set_ef(knn_hnsw_handle h, int32_t efSearch, int32_t efConstruction);
 /* walk tuning (not in faiss): candidates expanded per walker per lock-step round (default 8;
- * 1 = strict best-first) and walkers per batch (default 4096); values <= 0 keep the setting */
+ * 1 = strict best-first) and walkers / inserted rows per batch (default 16384); values <= 0 keep the setting */
 int knn_hnsw_set_walk(knn_hnsw_handle h, int32_t expand, int32_t max_batch);
 /* where the level-0 walk of a search starts (not in faiss): coarse_entries > 0 -- at the coarse_entries
  * nearest nodes above level 0, found by an exact scan of those rows on the flat kernel (default 4);

@@ -259,9 +259,10 @@ def test_rows_grouped_by_cluster_are_linked_like_shuffled_rows(gpu_faiss, monkey
     gpu_faiss.normalize_L2(x)
     shuffled = np.ascontiguousarray(x[rng.permutation(n)])
 
-    def recall_of(rows):
+    def recall_of(rows, calls=1):
         idx = gpu_faiss.IndexHNSWFlat(d, M, 0)
-        idx.add(rows)
+        for c in range(calls):
+            idx.add(rows[n * c // calls:n * (c + 1) // calls])
         idx.hnsw.efSearch = 128
         flat = gpu_faiss.IndexFlat(d, 0)
         flat.add(rows)
@@ -271,6 +272,11 @@ def test_rows_grouped_by_cluster_are_linked_like_shuffled_rows(gpu_faiss, monkey
         return _recall(I, It)
 
     r_grouped, r_shuffled = recall_of(x), recall_of(shuffled)
+    # the same rows added family by family, one `add` call each (a call is linked in eight batches at least: the later
+    # ones see the earlier ones)
+    r_calls = recall_of(x, calls=n // per)
+    print(f"recall@{k}: one add call per cluster {r_calls:.4f}")
+    assert r_calls >= r_shuffled - 0.02, (r_calls, r_shuffled)
     monkeypatch.setenv("KNN355_HNSW_ORDER", "sequential")
     r_old = recall_of(x)
     print(f"recall@{k}: grouped rows {r_grouped:.4f}, the same rows shuffled {r_shuffled:.4f}, grouped rows linked in their own order {r_old:.4f}")
