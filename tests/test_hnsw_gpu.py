@@ -284,6 +284,39 @@ def test_rows_grouped_by_cluster_are_linked_like_shuffled_rows(gpu_faiss, monkey
     assert r_old < r_grouped - 0.05, "the rows' own order should show the defect this test is about"
 
 
+def test_an_index_read_from_a_file_takes_more_rows(gpu_faiss, tmp_path):
+    """read_index imports the graph (every node linked, the device's lists rebuilt from the file's); rows added afterwards are
+    linked into it like rows added to the index that wrote the file.  (Not the SAME graph: the level generator's state is
+    not part of a FAISS file, the new nodes draw other levels -- the same quality.)"""
+    n0, n1, d, M, k = 30_000, 12_000, 64, 16, 20
+    x = _clustered(n0 + n1, d, 300, 41)
+    a = gpu_faiss.IndexHNSWFlat(d, M, 0)
+    a.add(x[:n0])
+    path = str(tmp_path / "first.index")
+    gpu_faiss.write_index(a, path)
+    b = gpu_faiss.read_index(path)
+    assert np.array_equal(a.graph()[2], b.graph()[2])
+    a.add(x[n0:])
+    b.add(x[n0:])
+    assert a.ntotal == b.ntotal == n0 + n1
+    levels, offsets, nbrs, cum, _ = b.graph()
+    for i in range(n0, n0 + n1, 97):  # every new node is linked on level 0
+        assert (nbrs[offsets[i]:offsets[i] + cum[1]] >= 0).sum() >= 1
+    q = np.ascontiguousarray(x[::37][:800])
+    a.hnsw.efSearch = b.hnsw.efSearch = 128
+    flat = gpu_faiss.IndexFlat(d, 0)
+    flat.add(x)
+    It = flat.search(q, k)[1]
+    ra, rb = _recall(a.search(q, k)[1], It), _recall(b.search(q, k)[1], It)
+    assert ra >= 0.95 and rb >= ra - 0.01, (ra, rb)
+    # and it can be written and read once more
+    path2 = str(tmp_path / "second.index")
+    gpu_faiss.write_index(b, path2)
+    c = gpu_faiss.read_index(path2)
+    c.hnsw.efSearch = 128
+    assert np.array_equal(c.search(q, k)[1], b.search(q, k)[1])
+
+
 def test_upper_levels_are_linked_on_a_graph_with_many_levels(gpu_faiss):
     """construction candidates of the levels >= 2 come from one top-2048 scan of the coarse index filtered
     by level; once the coarse index outgrows 2048 rows the highest levels' nodes are too rare in that scan (here: M = 4,
