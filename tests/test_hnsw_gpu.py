@@ -206,7 +206,7 @@ def test_graph_invariants_and_determinism(gpu_faiss):
 
 
 @pytest.mark.parametrize("metric,M,d,n,pieces,efc", [(0, 16, 64, 60_000, 1, 40), (1, 8, 96, 40_000, 3, 40), (0, 42, 256, 30_000, 2, 40),
-                                                     (1, 24, 64, 30_000, 1, 150)])
+                                                     (1, 24, 64, 30_000, 1, 150), (0, 63, 32, 24_000, 1, 40), (1, 2, 16, 12_000, 2, 40)])
 def test_device_links_build_the_host_links_graph(gpu_faiss, monkeypatch, metric, M, d, n, pieces, efc):
     """Construction keeps level 0 on the device since round 4 (candidates, forward selection, forward links, reverse requests
     sorted by (node, v, from), appended or pruned: hnsw.inc::hnsw_level0_links_device); KNN355_HNSW_HOST_LINKS=1 is the
