@@ -49,6 +49,12 @@ typedef const __attribute__((address_space(1))) f32x4 *gptr4; // explicit global
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define KEY_PAD 0xFFFFFFFFFFFFFFFFull
+#ifndef KNN355_DIFF_SCALAR_Q
+#define KNN355_DIFF_SCALAR_Q 1 // difference builds read their query fragments with scalar loads (0: broadcast LDS reads, round-4 first form)
+#endif
+#ifndef KNN355_DIFF_SCALAR_PAIRS
+#define KNN355_DIFF_SCALAR_PAIRS 3 // ... the first three query pairs of a thread's half (all of them up to 12 queries), the others through the LDS
+#endif
 #ifndef KNN355_STREAM_DMA_FIRST
 #define KNN355_STREAM_DMA_FIRST 1 // streaming launches issue a K step's staging instructions in front of its first MFMA (flat_scan_kernel)
 #endif
@@ -1175,6 +1181,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
         // staging instruction of the NEXT K step; the NI of them are spread between the MFMAs so
         // that their issue cost (60-180 cycles each) is paid while the matrix pipe is busy, not
         // in front of it.  ND = 0: nothing to stage.
+        int diff_koff = 0; // (difference builds) first float of the K step being multiplied
         auto compute = [&](const char *cur, auto &&dma, auto nd_tag) {
             constexpr int ND = decltype(nd_tag)::value;
             const char *A = cur;
@@ -1208,8 +1215,24 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
                 // 8t + 4 + 2u + 1 -- 16-byte slots 4 (t & 1) + u and 4 (t & 1) + 2 + u of staged row 2p + t / 2
                 auto loadq = [&](int hb) {
                     const int t = hb >> 1, u = hb & 1;
+                    // the first SQ query pairs of this thread's half come by SCALAR loads from the interleaved query matrix (the
+                    // address is the same for every lane; constant address space + an address made of scalars only: s_load_dwordx4
+                    // -- through a flat pointer the compiler takes vector loads and spills): they never touch the LDS pipe, which the
+                    // broadcast reads of the wider builds had saturated.  Three pairs at most: with every pair in scalar registers
+                    // the 16- / 20-query builds spill THOSE (9.7 / 12.5 ms per 10 M rows against 8.9 / 10.4 through the LDS)
+                    // (not in the 8-query build: it runs at the HBM rate either way, and with the lighter LDS load the chip settled on a
+                    // lower clock -- 6.60 against 6.31 ms per 10 M rows in steady state, three alternating runs on one box)
+                    constexpr int SQ = KNN355_DIFF_SCALAR_Q && NPH >= 3 ? (NPH < KNN355_DIFF_SCALAR_PAIRS ? NPH : KNN355_DIFF_SCALAR_PAIRS) : 0;
+                    typedef const __attribute__((address_space(4))) f32x4 *cq4;
 #pragma unroll
-                    for (int j = 0; j < NPH; j++) {
+                    for (int j = 0; j < SQ; j++) {
+                        const int pr = qh * NPH + j;
+                        const float *qg = p.xq_diff + (int64_t)(2 * pr + (t >> 1)) * p.dp + diff_koff + 4 * (4 * (t & 1) + u);
+                        qv[hb & 1][j][0] = *(cq4)qg;
+                        qv[hb & 1][j][1] = *(cq4)(qg + 8);
+                    }
+#pragma unroll
+                    for (int j = SQ; j < NPH; j++) {
                         const int pr = qh * NPH + j;
                         const char *qrow = B + (2 * pr + (t >> 1)) * 128;
                         const int fq = pr & 7; // ((2 pr) >> 1) & 7 -- the same for 2 pr + 1
@@ -1408,6 +1431,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
         for (int kt = 0; kt + 1 < KT; kt++) {
             char *cur = (kt & 1) ? stage1 : stage0;
             char *nxt = (kt & 1) ? stage0 : stage1;
+            diff_koff = kt * 32;
             // Stage kt has landed in LDS for EVERY wave's reads: this wave's staging instructions are waited for HERE,
             // explicitly, then the barrier.  (Nothing else orders a ds_read behind a pending LDS-DMA: until round 4 the wait
             // was the compiler's -- it puts a vmcnt(0) in front of LDS reads it cannot tell apart from a pending DMA's target
@@ -1423,6 +1447,7 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (see above)
         __syncthreads();
+        diff_koff = (KT - 1) * 32;
         compute(((KT - 1) & 1) ? stage1 : stage0, no_dma, nd_none{});
         if constexpr (!NTDB && !BF16) {
             if (p.cu_turn && tid == 0) __hip_atomic_store(my_turn, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
