@@ -317,6 +317,23 @@ def test_an_index_read_from_a_file_takes_more_rows(gpu_faiss, tmp_path):
     assert np.array_equal(c.search(q, k)[1], b.search(q, k)[1])
 
 
+def test_a_search_of_several_batches_equals_its_pieces(gpu_faiss):
+    """IndexHNSWFlat.search walks 16384 queries at a time; with several batches the results of batch b - 1 are downloaded
+    on the copy stream while batch b is walked (two sets of result buffers).  40 000 queries in one call = the same queries
+    in calls of one batch each, bit for bit -- and every row finds itself."""
+    n, d, M, k = 40_000, 48, 12, 30
+    x = _clustered(n, d, 200, 77)
+    idx = gpu_faiss.IndexHNSWFlat(d, M, 1)
+    idx.add(x)
+    idx.hnsw.efSearch = 64
+    D, I = idx.search(x, k)
+    assert (I[:, 0] == np.arange(n)).mean() > 0.98 and (D[I[:, 0] == np.arange(n), 0] == 0).all()
+    for a in range(0, n, 16384):
+        b = min(n, a + 16384)
+        Dp, Ip = idx.search(x[a:b], k)
+        assert np.array_equal(Ip, I[a:b]) and np.array_equal(Dp.view(np.uint32), D[a:b].view(np.uint32)), (a, b)
+
+
 def test_upper_levels_are_linked_on_a_graph_with_many_levels(gpu_faiss):
     """construction candidates of the levels >= 2 come from one top-2048 scan of the coarse index filtered
     by level; once the coarse index outgrows 2048 rows the highest levels' nodes are too rare in that scan (here: M = 4,
