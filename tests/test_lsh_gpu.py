@@ -65,6 +65,23 @@ def test_lsh_recall_and_roundtrip(gpu_faiss, tmp_path):
     assert np.array_equal(D, D2) and np.array_equal(I, I2) and back.ntotal == 200 and back.nbits == 1024
 
 
+def test_a_search_of_several_batches_equals_its_pieces(gpu_faiss):
+    """IndexLSH.search scans 16384 queries at a time; with several batches the results of batch b - 1 are downloaded on the
+    copy stream while batch b is scanned (two sets of result buffers): 40 000 queries in one call = the same queries in calls
+    of one batch each, bit for bit (pfam/search.py searches every row of its index, k = 1000)."""
+    n, d, nbits, k = 40_000, 64, 128, 25
+    x = np.random.default_rng(3).standard_normal((n, d)).astype(np.float32)
+    idx = gpu_faiss.IndexLSH(d, nbits)
+    idx.train(x)
+    idx.add(x)
+    D, I = idx.search(x, k)
+    assert (D[:, 0] == 0).all(), "every row's own code is at Hamming distance 0"
+    for a in range(0, n, 16384):
+        b = min(n, a + 16384)
+        Dp, Ip = idx.search(x[a:b], k)
+        assert np.array_equal(Ip, I[a:b]) and np.array_equal(Dp, D[a:b]), (a, b)
+
+
 def test_create_index_entry_point(gpu_faiss, tmp_path):
     """tests/test_utils.py:17-21 of the reference: the index file gets written."""
     from knn_for_homology_amd.seqvec_search import create_index
