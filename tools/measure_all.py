@@ -131,15 +131,21 @@ if "pfam" in sets:
         t0 = time.perf_counter()
         Dh, Ih = idx.search_self(k)
         t_self = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        Dh2, Ih2 = idx.search(xp, k)
-        t_host = time.perf_counter() - t0
-        assert np.array_equal(Ih, Ih2) and np.array_equal(Dh, Dh2)
+        # (twice: the second request of a result size class above 64 MB page-locks its block -- 0.2 s for 2.4 GB, once per
+        # process -- and the third finds it in the pool: _lib.result_array)
+        t_hosts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            Dh2, Ih2 = idx.search(xp, k)
+            t_hosts.append(time.perf_counter() - t0)
+            assert np.array_equal(Ih, Ih2) and np.array_equal(Dh, Dh2)
+            del Dh2, Ih2
+        t_host = min(t_hosts)
         # a duplicated row and its source tie on every score: they sit next to each other, lower id first
         a, b = np.minimum(dup_dst, dup_src), np.maximum(dup_dst, dup_src)
         first_two = np.sort(Ih[a, :2], axis=1)
         ok_dup = float(np.mean((first_two[:, 0] == a) & (first_two[:, 1] == b)))
-        r.update(frac_mfma_datasheet=r["tflops_scan"] / MFMA_PEAK, all_vs_all_self_s=t_self, all_vs_all_host_s=t_host,
+        r.update(frac_mfma_datasheet=r["tflops_scan"] / MFMA_PEAK, all_vs_all_self_s=t_self, all_vs_all_host_s=t_host, all_vs_all_host_calls_s=[round(t, 4) for t in t_hosts],
                  qps_all_vs_all_host=n / t_host, duplicate_pairs=int(a.size), duplicate_pairs_adjacent_lower_id_first=ok_dup)
         rows.append(r)
         log(f"S-pfam k={k:4d}: 16384-query batch scan {r['scan_ms']:.2f} ms ({r['tflops_scan']:.1f} TFLOP/s, {100*r['frac_mfma_datasheet']:.1f} %); "
