@@ -74,12 +74,87 @@ def parse():
     ap.add_argument("--no-batch", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the nq sweep, the host-buffer step and the HNSW run")
     ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only bring the N ranks up (gloo, CPU) and tear them down: exercises the bounded waits and the failure report")
     return ap.parse_args()
+
+
+# ---- bring-up of the N-rank run: bounded, and loud when it fails -------------------------------------------------
+# The first contact with an 8-GPU node must not end as a bare driver timeout.  Every wait of the bring-up has a bound:
+#   parent  preflight (enough GPUs?), the child torch.distributed.run under KNN355_BENCH_TIMEOUT_S (480 s), killed as the
+#           process group this process started; on a timeout or a non-zero exit the child's stderr tail and every rank's last
+#           progress marker go to stderr, the ranks that never brought their process group up are named, exit code != 0
+#   rank    init_process_group and every collective under KNN355_PG_TIMEOUT_S (120 s); a first tiny all-gather of the rank
+#           numbers proves the group before anything is timed (`ranks_seen` is what THAT gather returned)
+# Progress markers: one line per stage and rank in $KNN355_PROGRESS_DIR/rank<r>.log (the parent makes the directory).
+PG_TIMEOUT_S = float(os.environ.get("KNN355_PG_TIMEOUT_S", "120"))
+BENCH_TIMEOUT_S = float(os.environ.get("KNN355_BENCH_TIMEOUT_S", "480"))
+_T0 = time.time()
+
+
+def progress(stage):
+    """Rank side: append '<seconds since start> <stage>' to this rank's marker file (no-op outside a self-launched run)."""
+    pdir = os.environ.get("KNN355_PROGRESS_DIR")
+    if not pdir:
+        return
+    try:
+        with open(os.path.join(pdir, f"rank{os.environ.get('RANK', '0')}.log"), "a") as f:
+            f.write(f"{time.time() - _T0:8.2f} {stage}\n")
+    except OSError:
+        pass
+
+
+def read_progress(pdir, world):
+    """Parent side: {rank: [stages]} from the marker files (a rank that never started has none)."""
+    out = {}
+    for r in range(world):
+        try:
+            with open(os.path.join(pdir, f"rank{r}.log")) as f:
+                out[r] = [ln.split(None, 1)[1].strip() for ln in f if len(ln.split(None, 1)) == 2]
+        except OSError:
+            out[r] = []
+    return out
+
+
+def report_failed_launch(why, world, pdir, stderr_path):
+    """One diagnosis on stderr: why, each rank's last marker, the stalled ranks by name, the child's stderr tail."""
+    marks = read_progress(pdir, world)
+    print(f"bench.py: the {world}-rank run failed: {why}", file=sys.stderr)
+    for r in range(world):
+        print(f"bench.py:   rank {r}: last progress marker: {marks[r][-1] if marks[r] else '(none: the rank never started)'}", file=sys.stderr)
+    absent = [r for r in range(world) if not any(m.startswith("init_process_group") for m in marks[r])]  # never reached the rendezvous
+    down = [r for r in range(world) if "process_group_up" not in marks[r]]
+    if absent and len(absent) < world:
+        print(f"bench.py: rank(s) {', '.join(map(str, absent))} stalled before init_process_group; the other ranks waited "
+              f"KNN355_PG_TIMEOUT_S = {PG_TIMEOUT_S:.0f} s for them at the rendezvous and gave up", file=sys.stderr)
+    elif down:
+        print(f"bench.py: rank(s) {', '.join(map(str, down))} never got a process group (rendezvous at MASTER_ADDR:MASTER_PORT "
+              f"incomplete after {PG_TIMEOUT_S:.0f} s)", file=sys.stderr)
+    else:
+        late = [r for r in range(world) if "timed_steps_done" not in marks[r]]
+        if late:
+            print(f"bench.py: every rank joined; rank(s) {', '.join(map(str, late))} did not finish the timed steps", file=sys.stderr)
+    try:
+        with open(stderr_path, errors="replace") as f:
+            tail = f.read().splitlines()[-40:]
+        print("bench.py: ---- tail of the ranks' stderr ----", file=sys.stderr)
+        for ln in tail:
+            print("  " + ln, file=sys.stderr)
+    except OSError:
+        pass
 
 
 def self_launch(args):
     """`bench.py --gpus N` from a plain process: start the N ranks as a child torch.distributed.run.  This
-    process has not initialised the GPU (importing torch does not) and never will."""
+    process has not initialised the GPU (importing torch and counting devices do not) and never will."""
+    import signal
+    import tempfile
+    rehearse = os.environ.get("KNN355_REHEARSE_ONE_GPU", "0") == "1"
+    if not (rehearse or args.launch_check):
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s) (torch.cuda.device_count())", file=sys.stderr)
+            sys.exit(2)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -87,22 +162,103 @@ def self_launch(args):
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
-    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith('{"metric"')]
-    for ln in proc.stdout.splitlines():
-        if not ln.startswith('{"metric"'):
+    pdir = tempfile.mkdtemp(prefix="knn355_bench_")
+    env["KNN355_PROGRESS_DIR"] = pdir
+    stderr_path = os.path.join(pdir, "stderr.log")
+    t0 = time.time()
+    with open(stderr_path, "w") as errf:
+        # (a fresh child in its own session: on a timeout exactly the process group started HERE is killed)
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=errf, env=env, text=True, start_new_session=True)
+        try:
+            stdout, _ = proc.communicate(timeout=BENCH_TIMEOUT_S)
+            timed_out = False
+        except subprocess.TimeoutExpired:
+            timed_out = True
+            try:
+                os.killpg(proc.pid, signal.SIGTERM)
+                time.sleep(3)
+                os.killpg(proc.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            stdout, _ = proc.communicate()
+    lines = [ln for ln in (stdout or "").splitlines() if ln.startswith('{"metric"') or ln.startswith('{"launch_check"')]
+    for ln in (stdout or "").splitlines():
+        if ln not in lines:
             print(ln, file=sys.stderr)
-    if proc.returncode != 0 or len(lines) != 1:
-        print(f"bench.py: the {args.gpus}-rank run failed (exit code {proc.returncode}, {len(lines)} result lines)", file=sys.stderr)
-        sys.exit(proc.returncode or 1)
+    if timed_out or proc.returncode != 0 or len(lines) != 1:
+        why = (f"no result within KNN355_BENCH_TIMEOUT_S = {BENCH_TIMEOUT_S:.0f} s (killed)" if timed_out else
+               f"exit code {proc.returncode}, {len(lines)} result lines, after {time.time() - t0:.0f} s")
+        report_failed_launch(why, args.gpus, pdir, stderr_path)
+        sys.exit(124 if timed_out else (proc.returncode or 1))
+    try:  # (the ranks' stderr of a good run still goes where stderr goes)
+        with open(stderr_path, errors="replace") as f:
+            sys.stderr.write(f.read())
+    except OSError:
+        pass
+    import shutil
+    shutil.rmtree(pdir, ignore_errors=True)
     print(lines[0], flush=True)
     sys.exit(0)
+
+
+def bring_up(rank, world, backend, device=None):
+    """Rank side: the process group under PG_TIMEOUT_S, then ONE tiny all-gather of the rank numbers (bounded by the same
+    timeout) that proves the group.  Returns the ranks that gather saw.  KNN355_TEST_STALL_RANK / _S: a rank that sleeps in
+    front of init_process_group (the fail-fast test of tests/test_sharded_cpu.py)."""
+    import datetime
+    import torch.distributed as dist
+    progress("started")
+    if os.environ.get("KNN355_TEST_STALL_RANK", "") == str(rank):
+        progress("stalling (test hook)")
+        time.sleep(float(os.environ.get("KNN355_TEST_STALL_S", "60")))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    timeout = datetime.timedelta(seconds=PG_TIMEOUT_S)
+    progress(f"init_process_group({backend}) entered")
+    if backend == "gloo":
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timeout)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=timeout)
+    progress("process_group_up")
+    mine = torch.tensor([rank], dtype=torch.int64, device=device if backend != "gloo" else "cpu")
+    seen = torch.empty((world,), dtype=torch.int64, device=mine.device)
+    dist.all_gather_into_tensor(seen, mine)
+    seen = sorted(set(int(v) for v in seen.cpu().tolist()))
+    if seen != list(range(world)):
+        raise RuntimeError(f"bench.py: the first all-gather returned ranks {seen}, expected 0..{world - 1}")
+    progress("first_collective_ok")
+    return seen
+
+
+def rccl_version():
+    """RCCL's version as torch reports it (backend "nccl" IS RCCL on ROCm), e.g. "2.22.3"; None off a GPU build."""
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:  # noqa: BLE001 -- a label, never a reason to fail the run
+        return None
+
+
+def launch_check():
+    """`bench.py --gpus N --launch-check`: the bring-up alone (gloo on the CPU, no GPU work): what the fail-fast test runs,
+    and a ten-second preflight of a node's rendezvous."""
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    seen = bring_up(rank, world, "gloo")
+    dist.barrier()
+    progress("timed_steps_done")
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "ranks_seen": len(seen), "backend": "gloo", "pg_timeout_s": PG_TIMEOUT_S}), flush=True)
 
 
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args)
+    if args.launch_check:
+        launch_check()
+        return
     # stdout carries exactly ONE line (the JSON): everything libraries print while we run (RCCL's
     # version banner, for one) is sent to stderr instead
     sys.stdout.flush()
@@ -130,13 +286,11 @@ def run(args):
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     use_pg = world > 1 or os.environ.get("KNN355_FORCE_COLLECTIVE", "0") == "1"
+    ranks_first_gather = [0]
     if use_pg:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        if rehearse:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if not rehearse and torch.cuda.device_count() <= local_rank:
+            raise RuntimeError(f"bench.py: rank {rank} wants GPU {local_rank}, this node shows {torch.cuda.device_count()}")
+        ranks_first_gather = bring_up(rank, world, "gloo" if rehearse else "nccl", dev)
 
     from knn_for_homology_amd import _lib, faiss
     from knn_for_homology_amd.sharded import ShardedFlatIndex, shard_bounds
@@ -185,6 +339,7 @@ def run(args):
             torch.from_numpy(cpu_rows.array[i0:i0 + take]).copy_(x[:take])
         del x
     torch.cuda.synchronize()
+    progress("inputs_resident")
 
     in_flight = args.in_flight or (2 if world > 1 else 1)
 
@@ -206,6 +361,7 @@ def run(args):
     for pnd in warm:
         pnd.check()  # (a rank whose local scan failed raises here on every rank: sharded.ShardSearchError)
     del warm
+    progress("warmup_done")
     index.collective_events = [] if use_pg else None  # HIP event pairs around every all-gather of the timed steps
     pend = []
     t0 = time.perf_counter()
@@ -213,6 +369,7 @@ def run(args):
         pend.append(step())
     fence()
     elapsed = time.perf_counter() - t0
+    progress("timed_steps_done")
     for pnd in pend:  # (outside the timed region: the status rows of the K searches)
         pnd.check()
     D, I = pend[-1].result()
@@ -225,7 +382,7 @@ def run(args):
     if index.collective_events:
         gather_ms = float(np.mean([a.elapsed_time(b) for a, b in index.collective_events]))
     index.collective_events = None
-    ranks_seen = dist.get_world_size() if use_pg else 1
+    ranks_seen = len(ranks_first_gather) if use_pg else 1  # (what the first all-gather of the run returned, not the configured size)
 
     # ---- is the result right, and the same everywhere? (outside the timed region) --------------------------------
     # every planted row first for its query, with the score of a vector against itself; sorted best first; ids in range
@@ -321,6 +478,7 @@ def run(args):
     if use_pg:
         out["collective"] = {"op": "all_gather_into_tensor", "backend": "gloo (one-GPU rehearsal)" if rehearse else "nccl (RCCL)",
                              "bytes_per_rank": nq * k * 8, "avg_ms": gather_ms,
+                             "rccl_version": rccl_version(), "pg_timeout_s": PG_TIMEOUT_S,
                              "note": "HIP events on the lane's stream around the collective of every timed step (rank 0)"}
     basis = "HIP events around the scan launch on its stream"
     if avg_scan_ms and in_flight == 2:

@@ -183,18 +183,22 @@ class PendingSearch:
     A search over several ranks carries a status row through its all-gather (see
     ``ShardedFlatIndex._search_on_current_stream``): ``result()`` reads it (k x 8 bytes to the host, so the call waits
     for the search) and raises ``ShardSearchError`` on every rank if any rank's local scan failed.  ``result(check=False)``
-    only orders the streams; ``check()`` can be called later."""
+    only orders the streams; ``check()`` can be called later, from any stream: it always waits for the search's own event
+    first.  The status row has k slots: ``failed_ranks`` lists at most k ranks (the lowest ones)."""
 
     def __init__(self, D, I, event=None, status=None, local_error=None):
         self._D, self._I, self._event = D, I, event
+        self._status_event = event  # (kept until the status row has been read: result() may run on another stream than check())
         self._status, self._local_error = status, local_error
 
     def check(self):
         if self._status is not None:
-            if self._event is not None and self._status.is_cuda:  # (not yet ordered behind the lane's stream by result())
-                torch.cuda.current_stream(self._status.device).wait_event(self._event)
+            if self._status_event is not None and self._status.is_cuda:
+                # whatever stream is current now was not necessarily ordered behind the lane's stream by result()
+                torch.cuda.current_stream(self._status.device).wait_event(self._status_event)
             st = self._status.cpu()
             self._status = None
+            self._status_event = None
             failed = [int(r) for r in st.tolist() if r >= 0]
             if failed or self._local_error is not None:
                 raise ShardSearchError(failed, self._local_error) from self._local_error
@@ -230,6 +234,7 @@ class ShardedFlatIndex:
         # a list here makes every search append a (start, end) pair of timing events recorded on the lane's
         # stream around its all-gather (bench.py reports their mean)
         self.collective_events = None
+        self.unchecked = []  # searches of search_dev(check=False) whose status rows nobody has read yet
 
     @property
     def local(self):
@@ -304,12 +309,24 @@ class ShardedFlatIndex:
             done = side.record_event()
         return PendingSearch(D, I, done, status, err)
 
-    def search_dev(self, q, k):
+    def search_dev(self, q, k, check=True):
         """q: [nq, d] float32 tensor, identical on every rank.  Returns (D, I) tensors holding the
         global result on every rank, ordered after the search on the caller's current stream.  Over several ranks the
         call waits for the search's status row (``PendingSearch.result``) and raises ``ShardSearchError`` on every rank
-        if any rank failed; ``submit(...).result(check=False)`` stays asynchronous."""
-        return self.submit(q, k).result()
+        if any rank failed.  ``check=False`` leaves the status row unread and the host free to enqueue the next search:
+        the pending search is kept in ``self.unchecked`` and a caller that pipelines K searches calls ``check_pending()``
+        once behind them (what bench.py does with ``submit``)."""
+        pnd = self.submit(q, k)
+        if not check:
+            self.unchecked.append(pnd)
+        return pnd.result(check=check)
+
+    def check_pending(self):
+        """Reads the status rows of every ``search_dev(..., check=False)`` since the last call; raises
+        ``ShardSearchError`` (on every rank) for the first search that failed anywhere."""
+        pend, self.unchecked = self.unchecked, []
+        for pnd in pend:
+            pnd.check()
 
     def search(self, x: np.ndarray, k):
         _faiss._check_matrix(x, self.d)
@@ -340,6 +357,7 @@ class QueryShardedFlatIndex:
             rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.rank, self.world = rank, world
         self.backend = backend if backend is not None else DEFAULT_BACKEND(d, metric)
+        self.unchecked = []  # (status, local error) of gathered searches whose outcome nobody has read yet
 
     @property
     def ntotal(self):
@@ -369,9 +387,12 @@ class QueryShardedFlatIndex:
     def query_bounds(self, nq):
         return shard_bounds(nq, self.world, self.rank)
 
-    def search_dev(self, q, k, gather=False):
+    def search_dev(self, q, k, gather=False, check=True):
         """q: [nq, d] float32 tensor, identical on every rank.  Returns (D, I) of this rank's query slice
-        (``query_bounds(nq)``), or of all nq queries on every rank with ``gather=True``."""
+        (``query_bounds(nq)``), or of all nq queries on every rank with ``gather=True``.  A gathered search carries every
+        rank's outcome as one extra row of the id gather (no collective and no host round trip of its own in front of the
+        gathers); ``check=True`` reads those rows behind the gathers and raises ``ShardSearchError`` on every rank if any
+        rank's slice failed, ``check=False`` leaves them in ``self.unchecked`` for ``check_pending()``."""
         k = int(k)
         nq = q.shape[0]
         lo, hi = self.query_bounds(nq)
@@ -388,36 +409,48 @@ class QueryShardedFlatIndex:
             except Exception as e:  # noqa: BLE001
                 if not gather or self.world == 1:
                     raise
-                local_error = e  # (the peers are about to enter the gathers: agree on the outcome first)
+                local_error = e  # (the peers are about to enter the gathers: this rank enters them too, with its flag set)
+                D = torch.zeros((hi - lo, k), dtype=torch.float32, device=q.device)
+                I = torch.full((hi - lo, k), -1, dtype=torch.int64, device=q.device)
             finally:
                 if set_batch:
                     set_batch(0)
         if not gather or self.world == 1:
             return D, I
-        self._agree(local_error, q.device)
-        per = (nq + self.world - 1) // self.world
-        Dp = torch.zeros((per, k), dtype=torch.float32, device=q.device)
-        Ip = torch.full((per, k), -1, dtype=torch.int64, device=q.device)
-        Dp[: hi - lo] = D
-        Ip[: hi - lo] = I
-        Dg = torch.empty((self.world * per, k), dtype=torch.float32, device=q.device)
-        Ig = torch.empty((self.world * per, k), dtype=torch.int64, device=q.device)
+        Dg, Ig, status = self._gather_with_status(D, I, nq, k, q.device, local_error)
+        self.unchecked.append((status, local_error))
+        if check:
+            self.check_pending()
+        return Dg, Ig
+
+    def _gather_with_status(self, D, I, n, k, dev, local_error):
+        """Two all-gathers, rank-major: D padded to ceil(n / world) rows per rank, I to one row more -- the STATUS row, whose
+        first slot is 1 on a rank whose slice failed (every rank then knows, from the gather it was going to do anyway).
+        -> (D [n, k], I [n, k], status [world])."""
+        per = (n + self.world - 1) // self.world
+        m = D.shape[0]
+        Dp = torch.zeros((per, k), dtype=torch.float32, device=dev)
+        Ip = torch.full((per + 1, k), -1, dtype=torch.int64, device=dev)
+        Dp[:m] = D
+        Ip[:m] = I
+        Ip[per, 0] = 0 if local_error is None else 1
+        Dg = torch.empty((self.world * per, k), dtype=torch.float32, device=dev)
+        Ig = torch.empty((self.world * (per + 1), k), dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(Dg, Dp, group=self.group)
         dist.all_gather_into_tensor(Ig, Ip, group=self.group)
-        # (contiguous slices of ceil(nq/world) queries: rank-major concatenation is query order)
-        return Dg[:nq], Ig[:nq]
+        Ig = Ig.view(self.world, per + 1, k)
+        status = Ig[:, per, 0]
+        # (contiguous slices of ceil(n / world) queries: rank-major concatenation is query order, once the status rows are out)
+        return Dg[:n], Ig[:, :per].reshape(self.world * per, k)[:n], status
 
-    def _agree(self, local_error, device=None):
-        """In front of the result gathers: did every rank's slice succeed?  One all-gather of a flag per rank; a failure
-        anywhere raises ``ShardSearchError`` on EVERY rank instead of leaving the healthy ones inside the gathers."""
-        on_gpu = dist.get_backend(self.group) == "nccl"
-        dev = (device if device is not None and device.type == "cuda" else getattr(self.backend, "device", torch.device("cpu"))) if on_gpu else torch.device("cpu")
-        flag = torch.tensor([0 if local_error is None else 1], dtype=torch.int32, device=dev)
-        flags = torch.empty((self.world,), dtype=torch.int32, device=dev)
-        dist.all_gather_into_tensor(flags, flag, group=self.group)
-        failed = [r for r, f in enumerate(flags.cpu().tolist()) if f]
-        if failed:
-            raise ShardSearchError(failed, local_error) from local_error
+    def check_pending(self):
+        """Reads the status rows of the gathered searches since the last call (one small device-to-host copy each); a
+        failure anywhere raises ``ShardSearchError`` on EVERY rank."""
+        pend, self.unchecked = self.unchecked, []
+        for status, local_error in pend:
+            failed = [r for r, f in enumerate(status.cpu().tolist()) if f]
+            if failed:
+                raise ShardSearchError(failed, local_error) from local_error
 
     def normalize_rows(self):
         """L2-normalises the replica's rows in HBM (every rank: the same rows, the same bits)"""
@@ -447,22 +480,17 @@ class QueryShardedFlatIndex:
                 set_batch(0)
         if not gather or self.world == 1:
             return D, I
-        self._agree(local_error)
-        per = (n + self.world - 1) // self.world
         # gloo gathers host tensors, RCCL device tensors
         on_gpu = dist.get_backend(self.group) == "nccl"
         dev = getattr(self.backend, "device", torch.device("cpu")) if on_gpu else torch.device("cpu")
-        Dp = torch.zeros((per, k), dtype=torch.float32, device=dev)
-        Ip = torch.full((per, k), -1, dtype=torch.int64, device=dev)
-        Dp[: hi - lo] = torch.from_numpy(D).to(dev)
-        Ip[: hi - lo] = torch.from_numpy(I).to(dev)
-        Dg = torch.empty((self.world * per, k), dtype=torch.float32, device=dev)
-        Ig = torch.empty((self.world * per, k), dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(Dg, Dp, group=self.group)
-        dist.all_gather_into_tensor(Ig, Ip, group=self.group)
+        if local_error is not None:
+            D, I = np.zeros((hi - lo, k), np.float32), np.full((hi - lo, k), -1, np.int64)
+        Dg, Ig, status = self._gather_with_status(torch.from_numpy(D).to(dev), torch.from_numpy(I).to(dev), n, k, dev, local_error)
         if on_gpu:
             torch.cuda.current_stream(dev).synchronize()
-        return Dg[:n].cpu().numpy(), Ig[:n].cpu().numpy()
+        self.unchecked.append((status, local_error))
+        self.check_pending()
+        return Dg.cpu().numpy(), Ig.cpu().numpy()
 
     def search(self, x: np.ndarray, k, gather=True):
         _faiss._check_matrix(x, self.d)

@@ -32,6 +32,16 @@ What it does
    reference's pinned numpy 1.22.2 (``poetry.lock:222-223``) it is evaluated in double;
    the product follows whichever numpy its caller runs.
 
+5. ``--hnsw-refshape`` (opt-in: ~15 minutes of one core, no reference import): builds
+   ``oracle/hnsw_oracle.c``'s SEQUENTIAL graph on the S-pfam stand-in at the reference's size
+   and shape -- 200 000 x 1024 clustered rows (the generator of
+   ``tests/test_hnsw_gpu.py::test_reference_shape_at_pfam_size``), M = 42, inner product,
+   efConstruction 40 (``pfam/proteins_search.py:27-31``) -- walks the 2048 sampled queries of
+   that test with ef = max(efSearch, k) = 1000 (``pfam/proteins_search.py:49``: k = 1000) and
+   saves recall@100 / @300 / @1000 against the oracle's exact flat search, the query ids and
+   the oracle's hit ids as ``hnsw_refshape_200k.npz``: the algorithm's own figure at the size
+   the device is measured at.
+
 Nothing from the reference's *source* is copied; only data files.
 """
 import json
@@ -218,7 +228,53 @@ def oracle_vectors():
         print(ds, "written")
 
 
+def hnsw_refshape():
+    """The sequential oracle at the reference's HNSW shape AND size (see the module docstring, step 5)."""
+    import time
+    n, d, k, M, efc, ef = 200_000, 1024, 1000, 42, 40, 1000
+    rng = np.random.default_rng(21)  # == tests/test_hnsw_gpu.py::_clustered(n, d, 2000, 21)
+    cent = rng.standard_normal((2000, d), dtype=np.float32)
+    x = cent[rng.integers(0, 2000, n)] + 0.35 * rng.standard_normal((n, d), dtype=np.float32)
+    orc = ko.oracle()
+    orc.normalize_l2(x)
+    sample = np.arange(0, n, 97)[:2048]
+    q = np.ascontiguousarray(x[sample])
+    t0 = time.time()
+    _, It = orc.flat_search(x, q, k, ko.METRIC_INNER_PRODUCT)
+    print(f"exact flat search of the {len(sample)} sampled queries: {time.time() - t0:.0f} s", flush=True)
+    h = ko.OracleHNSW(d, M, ko.METRIC_INNER_PRODUCT, efc)
+    t0 = time.time()
+    step = 20_000
+    for r0 in range(0, n, step):  # (sequential insertion: the split into calls changes nothing)
+        h.add(x[r0:r0 + step])
+        print(f"  {r0 + step} rows linked, {time.time() - t0:.0f} s", flush=True)
+    build_s = time.time() - t0
+    t0 = time.time()
+    _, Ir = h.search(q, k, ef)
+    search_s = time.time() - t0
+    rec = lambda a, b: sum(len(np.intersect1d(u[u >= 0], v)) for u, v in zip(a, b)) / b.size
+    out = {
+        "n": n, "d": d, "k": k, "M": M, "ef_construction": efc, "ef": ef, "seed": 21, "ncent": 2000,
+        "sample": sample.astype(np.int32),
+        "recall_at_100": rec(Ir[:, :100], It[:, :100]),
+        "recall_at_300": rec(Ir[:, :300], It[:, :300]),
+        "recall_at_1000": rec(Ir, It),
+        "self_first": float((Ir[:, 0] == sample).mean()),
+        # the oracle's hits: every query down to rank 300 (what pfam/proteins.py:41,246 read), the first 256 queries in full
+        "oracle_I_300": Ir[:, :300].astype(np.int32),
+        "oracle_I_1000_first256": Ir[:256].astype(np.int32),
+        "exact_I_1000_first256": It[:256].astype(np.int32),
+        "build_seconds": build_s, "search_seconds": search_s,
+    }
+    np.savez_compressed(HERE / "hnsw_refshape_200k.npz", **out)
+    print("hnsw_refshape_200k.npz:", {k_: float(out[k_]) for k_ in ("recall_at_100", "recall_at_300", "recall_at_1000", "self_first")},
+          f"build {build_s:.0f} s, search {search_s:.0f} s")
+
+
 if __name__ == "__main__":
+    if "--hnsw-refshape" in sys.argv:
+        hnsw_refshape()
+        sys.exit(0)
     copy_fixtures()
     reference_driven()
     reference_consumers()

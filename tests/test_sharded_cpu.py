@@ -142,6 +142,15 @@ def _worker_failing(rank, world, port, out_dir):
         res["raised_async"] = 0
     except ShardSearchError:
         res["raised_async"] = 1
+    # search_dev(check=False): the status row stays unread (the host is free to enqueue the next search), check_pending()
+    # reads it later -- and only once
+    idx.search_dev(torch.from_numpy(xq), 5, check=False)
+    try:
+        idx.check_pending()
+        res["raised_deferred"] = 0
+    except ShardSearchError as e:
+        res["raised_deferred"] = 1 if e.failed_ranks == [1] else -1
+    idx.check_pending()  # (nothing pending any more)
     idx.backend.fail_search_keys = None
     D, I = idx.search(xq, 5)
     res["D"], res["I"] = D, I
@@ -156,6 +165,13 @@ def _worker_failing(rank, world, port, out_dir):
     except ShardSearchError as e:
         res["qs_raised"] = 1
         res["qs_failed"] = np.array(e.failed_ranks)
+    # the outcome rides in the id gather (no collective of its own): check=False defers reading it
+    qs.search_dev(torch.from_numpy(xq), 5, gather=True, check=False)
+    try:
+        qs.check_pending()
+        res["qs_deferred"] = 0
+    except ShardSearchError as e:
+        res["qs_deferred"] = 1 if e.failed_ranks == [1] else -1
     np.savez(Path(out_dir) / f"f{rank}.npz", **res)
     dist.barrier()
     dist.destroy_process_group()
@@ -330,6 +346,7 @@ def test_a_failing_rank_raises_on_every_rank(tmp_path):
         assert got["raised_async"] == 1
         assert np.array_equal(got["I"], Io) and np.array_equal(got["D"].view(np.uint32), Do.view(np.uint32)), "the search after the failure"
         assert got["qs_raised"] == 1 and got["qs_failed"].tolist() == [1]
+        assert got["raised_deferred"] == 1 and got["qs_deferred"] == 1, "check=False defers the status, check_pending() raises it"
 
 
 def _worker_rank0_only(rank, world, port, out_dir):
@@ -368,3 +385,48 @@ def test_shard_bounds_cover_everything():
             spans = [shard_bounds(n, w, r) for r in range(w)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def _run_launch_check(n, extra_env, timeout):
+    import subprocess
+    import time
+    env = dict(os.environ)
+    env.update(extra_env)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", str(n), "--launch-check"], env=env, text=True,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    return p, time.time() - t0
+
+
+def test_bench_bring_up_of_four_ranks():
+    """`bench.py --gpus 4 --launch-check`: the parent's preflight / child launch / result collection and the ranks' bounded
+    bring-up (init_process_group + the first all-gather of the rank numbers), on gloo."""
+    import json
+    p, _ = _run_launch_check(4, {}, 170)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["launch_check"] is True and line["ranks_seen"] == 4
+
+
+def test_bench_with_a_stalled_rank_fails_fast_and_names_it():
+    """one rank of four sleeps in front of init_process_group.  The other three give up after
+    KNN355_PG_TIMEOUT_S (120 s by default; 8 s here), the launcher exits non-zero well inside the driver's budget -- never a
+    bare timeout -- and its report names the stalled rank and shows every rank's last progress marker."""
+    p, took = _run_launch_check(4, {"KNN355_PG_TIMEOUT_S": "8", "KNN355_TEST_STALL_RANK": "2", "KNN355_TEST_STALL_S": "120"}, 170)
+    assert p.returncode != 0
+    assert took < 150, took
+    assert "rank(s) 2 stalled before init_process_group" in p.stderr, p.stderr[-3000:]
+    assert "rank 2: last progress marker: stalling (test hook)" in p.stderr
+    for r in (0, 1, 3):
+        assert f"rank {r}: last progress marker: init_process_group(gloo) entered" in p.stderr
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")], "no result line from a failed run"
+
+
+def test_bench_parent_timeout_kills_the_run_it_started():
+    """The launcher's own bound (KNN355_BENCH_TIMEOUT_S, 480 s by default): every rank stalls -> the child is killed as a
+    process group, exit code 124, the report says so."""
+    p, took = _run_launch_check(2, {"KNN355_BENCH_TIMEOUT_S": "12", "KNN355_PG_TIMEOUT_S": "100", "KNN355_TEST_STALL_RANK": "1",
+                                   "KNN355_TEST_STALL_S": "100"}, 120)
+    assert p.returncode == 124 and took < 60, (p.returncode, took)
+    assert "no result within KNN355_BENCH_TIMEOUT_S = 12 s (killed)" in p.stderr
+    assert "rank(s) 1 stalled before init_process_group" in p.stderr
