@@ -39,6 +39,7 @@ extern "C" {
 #define KNN_ERR_HIP (-3)
 #define KNN_ERR_UNSUPPORTED (-4)
 #define KNN_ERR_IO (-5)
+#define KNN_ERR_TIMEOUT (-6) /* a bounded wait of the multi-GPU path ran out (knn_comm_create, knn_sharded_search_dev) */
 
 /* largest k the fused top-k supports (the reference uses k <= 1000:
  * pfam/proteins_search.py:49) */
@@ -153,7 +154,11 @@ void knn_free(knn_handle h);
  * stream waits (on the GPU) for the previous call's selection.  Two searches in flight need two
  * communicators.  A rank whose local scan fails still enters the all-gather with "no rows" so
  * that its peers do not deadlock, and returns its error: a failure on ANY rank is a failure of
- * the search -- exchange the return codes before trusting a result. */
+ * the search -- exchange the return codes before trusting a result.
+ * Bounded waits: knn_comm_create gives a peer KNN355_COMM_TIMEOUT_S seconds (environment; default 120) to
+ * arrive, the synchronous form of knn_sharded_search_dev (stream == NULL) gives the search the same time to
+ * complete; both return KNN_ERR_TIMEOUT with the rank named in knn_last_error() instead of hanging, and the
+ * communicator is unusable afterwards (free it). */
 typedef struct knn_comm_s *knn_comm;
 int knn_comm_unique_id(uint8_t *id128);
 int knn_comm_create(const uint8_t *id128, int32_t world, int32_t rank, int32_t device, knn_comm *out);

@@ -35,6 +35,8 @@
 #include <math.h>
 #include <algorithm>
 #include <mutex>
+#include <condition_variable>
+#include <chrono>
 #include <memory>
 #include <atomic>
 #include <string>
@@ -3501,7 +3503,10 @@ static int search_failed(knn_index_s *h, bool *failed)
         h->stat_redo++;
         // read = cleared: a search whose predecessor left the level's state reset (LevelBufs::clean_sig) skips the launch
         // that clears the flag, and a repeat that returns early with an error never reaches its own
-        HIP_TRY(hipMemset(h->ws_flag.p, 0, 4));
+        // (on the handle's stream, like every other access to the flag: a NULL-stream memset is not ordered against a
+        // non-blocking stream, and completing late it could erase the flag of the repeat search -- ADVICE r4)
+        HIP_TRY(hipMemsetAsync(h->ws_flag.p, 0, 4, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
     }
     return 0;
 }
@@ -3712,6 +3717,10 @@ static int self_search_symmetric(knn_index_s *h, int k, float *D_dev, int64_t *I
 #endif
     // 2 + 3. the launches, each followed by the final selection of the rows it completes (verified against the sample's bound)
     hipEvent_t gev[SYM_GROUPS] = {};
+    struct GroupEvents { // (the events of this call go with it, whichever way it returns -- ADVICE r4)
+        hipEvent_t *e;
+        ~GroupEvents() { for (int i = 0; i < SYM_GROUPS; i++) if (e[i]) (void)hipEventDestroy(e[i]); }
+    } gev_guard{gev};
     for (int g = 0; g < groups; g++) {
         const size_t g0 = (size_t)h->sym_gstart[(size_t)g], g1 = (size_t)h->sym_gstart[(size_t)g + 1];
         for (size_t i0 = g0; i0 < g1; i0 += (size_t)max_wgs) {
@@ -3749,9 +3758,9 @@ static int self_search_symmetric(knn_index_s *h, int k, float *D_dev, int64_t *I
         if (e == hipSuccess && r1 > r0) e = hipMemcpyAsync(D_host + (size_t)r0 * k, D_dev + (size_t)r0 * k, (size_t)(r1 - r0) * k * 4, hipMemcpyDeviceToHost, d2h);
         if (e == hipSuccess && r1 > r0) e = hipMemcpyAsync(I_host + (size_t)r0 * k, I_dev + (size_t)r0 * k, (size_t)(r1 - r0) * k * 8, hipMemcpyDeviceToHost, d2h);
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(d2h);
-    for (int g = 0; g < groups; g++)
-        if (gev[g]) (void)hipEventDestroy(gev[g]);
+    // (always: a copy already queued writes into the caller's arrays)
+    const hipError_t es = hipStreamSynchronize(d2h);
+    if (e == hipSuccess) e = es;
     if (e != hipSuccess) return set_err(KNN_ERR_HIP, hipGetErrorString(e));
     return 2;
 }
@@ -4415,6 +4424,14 @@ static int rccl_load()
         if (r_ != 0) return set_err(KNN_ERR_HIP, std::string(#expr) + ": " + g_rccl.GetErrorString(r_));      \
     } while (0)
 
+// how long a rank waits for its peers (communicator creation, a synchronous sharded search): KNN355_COMM_TIMEOUT_S, default 120 s
+static double comm_timeout_s()
+{
+    const char *e = getenv("KNN355_COMM_TIMEOUT_S");
+    const double v = e ? atof(e) : 120.0;
+    return v > 0 ? v : 120.0;
+}
+
 struct knn_comm_s {
     void *comm = nullptr;
     int world = 1, rank = 0, device = 0;
@@ -4446,11 +4463,47 @@ extern "C" int knn_comm_create(const uint8_t *id128, int32_t world, int32_t rank
     c->device = device;
     Id128 id;
     memcpy(id.b, id128, 128);
-    int r = g_rccl.CommInitRank(&c->comm, world, id, rank);
-    if (r != 0) {
-        delete c;
-        return set_err(KNN_ERR_HIP, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r));
+    // ncclCommInitRank returns when EVERY rank has called it -- with a peer that never arrives, never.  It runs on a helper
+    // thread and this call waits for it at most KNN355_COMM_TIMEOUT_S seconds (120): the first contact with a multi-GPU node
+    // fails with the rank named, not as a hang.  (A helper that is still inside RCCL when the wait runs out is left to itself:
+    // it owns its state and destroys the communicator should the call ever return.)
+    struct InitState {
+        std::mutex mu;
+        std::condition_variable cv;
+        bool finished = false, abandoned = false;
+        int r = 0;
+        void *comm = nullptr;
+    };
+    auto st = std::make_shared<InitState>();
+    std::thread([st, id, world, rank, device]() {
+        int r = hipSetDevice(device) == hipSuccess ? 0 : -1; // (the communicator belongs to the calling thread's current device)
+        void *comm = nullptr;
+        if (r == 0) r = g_rccl.CommInitRank(&comm, world, id, rank);
+        std::unique_lock<std::mutex> lk(st->mu);
+        st->r = r;
+        st->comm = comm;
+        st->finished = true;
+        if (st->abandoned && r == 0 && comm) (void)g_rccl.CommDestroy(comm);
+        st->cv.notify_all();
+    }).detach();
+    const double wait_s = comm_timeout_s();
+    {
+        std::unique_lock<std::mutex> lk(st->mu);
+        if (!st->cv.wait_for(lk, std::chrono::duration<double>(wait_s), [&] { return st->finished; })) {
+            st->abandoned = true;
+            delete c;
+            char msg[256];
+            snprintf(msg, sizeof msg, "comm_create: rank %d of %d: ncclCommInitRank did not return within %.0f s (KNN355_COMM_TIMEOUT_S) -- "
+                                      "a peer never arrived, or the ranks do not share the unique id", rank, world, wait_s);
+            return set_err(KNN_ERR_TIMEOUT, msg);
+        }
     }
+    if (st->r != 0) {
+        delete c;
+        return set_err(KNN_ERR_HIP, st->r == -1 ? std::string("comm_create: hipSetDevice failed on the helper thread")
+                                               : std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(st->r));
+    }
+    c->comm = st->comm;
     *out = c;
     return 0;
 }
@@ -4515,7 +4568,29 @@ extern "C" int knn_sharded_search_dev(knn_handle h, knn_comm_s *c, const float *
     rc = launch_select(sp, s);
     (void)hipEventRecord(c->done, s);
     if (rc) return rc;
-    if (!stream) HIP_TRY(hipStreamSynchronize(s));
+    if (!stream) {
+        if (c->world == 1) {
+            HIP_TRY(hipStreamSynchronize(s));
+        } else {
+            // bounded: a peer that never enters the all-gather would hold hipStreamSynchronize for ever
+            const double wait_s = comm_timeout_s();
+            const auto t0 = std::chrono::steady_clock::now();
+            int spins = 0;
+            for (;;) {
+                const hipError_t q = hipStreamQuery(s);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) return set_err(KNN_ERR_HIP, std::string("sharded_search: ") + hipGetErrorString(q));
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > wait_s) {
+                    char msg[256];
+                    snprintf(msg, sizeof msg, "sharded_search: rank %d of %d: the search (local scan, ncclAllGather, selection) did not complete within "
+                                              "%.0f s (KNN355_COMM_TIMEOUT_S) -- a peer never entered the all-gather; the communicator is unusable", c->rank, c->world, wait_s);
+                    return set_err(KNN_ERR_TIMEOUT, msg);
+                }
+                if (++spins < 2000) std::this_thread::yield(); // (a healthy step takes a millisecond: stay close for the first ones)
+                else std::this_thread::sleep_for(std::chrono::microseconds(200));
+            }
+        }
+    }
     return 0;
 }
 

@@ -3,6 +3,8 @@ beam rows re-scored with the flat search's arithmetic).  FAISS's own HNSW graph 
 deterministic under OpenMP, so parity is stated the way the north star does: recall@k
 against the exact flat search, plus bit-equality of every returned distance with the flat
 kernel's distance for the same (query, row)."""
+from pathlib import Path
+
 import numpy as np
 import pytest
 
@@ -602,5 +604,19 @@ def test_reference_shape_at_pfam_size(gpu_faiss):
     # 1e-2 among 2000 equidistant clusters; the sequential oracle loses the same ranks at the sizes it can build -- see
     # the test above and tests/probe_hnsw_reference_shape.py: 40 k rows of this structure, oracle 0.902, device 0.911)
     assert r >= 0.78 and r100 >= 0.99, (r, r100)
+    # The algorithm's own figure AT THIS SIZE: oracle/hnsw_oracle.c's sequential build of these very rows
+    # (same generator and seed, M = 42, efConstruction 40), walked with ef = 1000 for these 2048 queries in the build container
+    # (tests/golden/make_golden.py --hnsw-refshape: 207 s of one core) -- recall@100 0.951, @300 0.878, @1000 0.744 against the
+    # oracle's exact flat search.  The device must not be worse than the oracle by more than 2 points at any depth.
+    g = np.load(Path(__file__).resolve().parent / "golden" / "hnsw_refshape_200k.npz")
+    assert int(g["n"]) == n and int(g["d"]) == d and int(g["M"]) == 42 and np.array_equal(g["sample"], sample)
+    # the fixture's ids against the device's exact search: the stored recalls are reproduced (fp32 ties aside)
+    o300 = g["oracle_I_300"].astype(np.int64)
+    assert abs(_recall(o300[:, :100], It[:, :100]) - float(g["recall_at_100"])) < 2e-3
+    assert abs(_recall(o300, It[:, :300]) - float(g["recall_at_300"])) < 2e-3
+    assert _recall(g["exact_I_1000_first256"].astype(np.int64), It[:256]) > 0.9995, "same rows, same exact neighbours"
+    print(f"sequential oracle at this size: recall@100 {float(g['recall_at_100']):.4f}, @300 {float(g['recall_at_300']):.4f}, "
+          f"@1000 {float(g['recall_at_1000']):.4f}; device {r100:.4f} / {r300:.4f} / {r:.4f}")
+    assert r100 >= float(g["recall_at_100"]) - 0.02 and r300 >= float(g["recall_at_300"]) - 0.02 and r >= float(g["recall_at_1000"]) - 0.02
     hits, scores = remove_self_hit(I[:4096].copy(), D[:4096].copy())
     assert hits.shape == (4096, k - 1)

@@ -5,11 +5,13 @@ a 4-shard exchange is emulated by concatenating per-shard key lists on the devic
 import ctypes
 import os
 import socket
+from pathlib import Path
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
 
 
 def _free_port():
@@ -144,6 +146,37 @@ def test_in_library_rccl_single_rank(gpu_faiss, oracle):
         assert L.knn_comm_create(ident, 2, 2, 0, ctypes.byref(ctypes.c_void_p())) != 0  # rank out of range
     finally:
         L.knn_comm_free(comm)
+
+
+_ABSENT_PEER = r"""
+import ctypes, os, sys, time
+sys.path.insert(0, sys.argv[1])
+import torch
+from knn_for_homology_amd import _lib
+L = _lib.lib()
+_lib.check(L.knn_init(0))
+ident = (ctypes.c_uint8 * 128)()
+_lib.check(L.knn_comm_unique_id(ident))
+comm = ctypes.c_void_p()
+t0 = time.time()
+rc = L.knn_comm_create(ident, 2, 0, 0, ctypes.byref(comm))   # rank 0 of 2; rank 1 never calls
+took = time.time() - t0
+msg = L.knn_last_error().decode()
+print(f"rc={rc} took={took:.1f} msg={msg}", flush=True)
+os._exit(0 if (rc == -6 and took < 30 and "rank 0 of 2" in msg and "did not return within" in msg) else 1)
+"""
+
+
+def test_in_library_comm_create_gives_up_on_an_absent_peer(tmp_path):
+    """VERDICT r4 item 3 (the in-library path): knn_comm_create(world = 2) with a peer that never calls returns
+    KNN_ERR_TIMEOUT after KNN355_COMM_TIMEOUT_S seconds, naming the rank -- it does not hang.  In a process of its own
+    (left with os._exit: the abandoned helper thread is still inside ncclCommInitRank)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, KNN355_COMM_TIMEOUT_S="6")
+    p = subprocess.run([sys.executable, "-c", _ABSENT_PEER, str(ROOT)], env=env, text=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=180)
+    assert p.returncode == 0, p.stdout[-2000:]
 
 
 def test_query_sharded_slices_equal_the_unsharded_search(gpu_faiss, oracle):
