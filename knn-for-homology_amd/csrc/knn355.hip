@@ -708,8 +708,10 @@ struct ScanParams {
 };
 #ifdef KNN355_TRACE
 #define KNN_TRACE(slot) do { if (threadIdx.x == 0 && p.trace && (slot) < 128) p.trace[(size_t)blockIdx.x * 128 + (slot)] = wall_clock64(); } while (0)
+#define KNN_TRACE_AT(cond, slot) do { if (cond) KNN_TRACE(slot); } while (0)
 #else
 #define KNN_TRACE(slot) do { } while (0)
+#define KNN_TRACE_AT(cond, slot) do { } while (0)
 #endif
 
 // Views: view row r of a launch with stride row_mul and block size B = 1 << vshift is database row
@@ -918,6 +920,19 @@ __device__ __forceinline__ void stage_issue(const float *src, char *lds_wave_bas
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, NT ? 2 : 0);
 }
 
+// scheduling pattern "one MFMA, one LDS read", N times: a sub-step's fragment reads go out one per MFMA -- four waves that
+// issue eight ds_read_b128 each in one burst keep the LDS array busy for two MFMA times (one wave per SIMD: 3.5 % of the
+// 256 x 256 tile's K loop, measured by ablation)
+template <int N>
+__device__ __forceinline__ void sched_reads()
+{
+    if constexpr (N > 0) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        sched_reads<N - 1>();
+    }
+}
+
 // scheduling pattern "PER MFMAs, one vector-memory instruction", N times
 template <int N, int PER>
 __device__ __forceinline__ void sched_spread()
@@ -963,8 +978,12 @@ __device__ __forceinline__ void sched_spread()
 // 8t + {2, 6, 3, 7}[g] per block of 8) instead of TN blocks of 32: a 48-query tile (4 x 1 waves, 33..48 queries) and a
 // 96-query tile (2 x 2 waves, 65..96 queries) pay for 48 / 96 columns of matrix work, not 64 / 128.  One-query-tile launches
 // only (plain fp32).
+// TM x TN = 4 x 4 ("BIG", round 5): a 256 x 256 tile on four waves, ONE workgroup per CU, one wave per SIMD with up to 512
+// registers -- 256 of them the wave's 128 x 128 accumulators (AGPRs), 128 KB of LDS for the two staging buffers.  Half the
+// staged bytes per flop of the 128 x 128 tile, a quarter of the K-step barriers and first-fragment waits per flop; nothing
+// else on the CU fills the epilogue's gaps, so this build is for long chunks only (make_plan).
 template <int WM, int WN, int TM, int TN, bool L2, bool NTDB = false, bool SYM = false, bool BF16 = false, int DNQ = 0, int Q16 = 0>
-__global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
+__global__ __launch_bounds__(256, (TM * TN >= 16 ? 1 : 2)) void flat_scan_kernel(ScanParams p)
 {
     constexpr bool DIFF = DNQ > 0; // the difference build, for batches of up to DNQ queries (8, 12, 16 or 20)
     static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -1098,6 +1117,20 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
             my_turn = p.cu_turn + ((xcc << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u));
         }
     }
+    // (256 x 256 builds) what the sparse epilogue needs per query block and never changes: the queries' norms, and which lanes'
+    // queries may be candidates of the symmetric launch's second direction (real rows the sample pass has not handed on)
+    float big_xnq[NB];
+    uint64_t big_cokm[NB];
+    if constexpr (TM * TN >= 16) {
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const int64_t q = q0 + (M16 ? 0 : (wn * TN + b) * 32 + li);
+            const bool qok = q < p.nq;
+            big_xnq[b] = 0.0f;
+            if constexpr (L2) big_xnq[b] = p.xn[qok ? q : 0];
+            big_cokm[b] = __ballot(qok && !(p.skip_mask >= 0 && ((int)(q >> p.vshift) & p.skip_mask) == 0));
+        }
+    }
     int tile_idx = 0; // tiles this workgroup has walked
     // the tile being walked / the one after it, as tile numbers of the view (-1: none)
     int cur_tile = paired ? (side == 0 ? tile_first : tile_first + n_own - 1) : tile_first;
@@ -1110,6 +1143,8 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
         p.trace[(size_t)blockIdx.x * 128 + 62] = ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32) | (unsigned)__builtin_amdgcn_s_getreg(0xF804);
 #endif
     int64_t first_row0 = c_lo;
+    const float *tsrc[NI]; // this lane's source of each of its staging instructions for the tile being walked (first K step)
+    bool staged0 = false;  // (256 x 256 builds) K step 0 of the tile about to start is already on its way into buffer 0
     while (cur_tile >= 0) {
         const int64_t row0 = (int64_t)cur_tile * DT;
         if (tile_idx == 0) first_row0 = row0;
@@ -1158,14 +1193,15 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
 #pragma unroll
         for (int qi = 0; qi < (DIFF_NQ + 1) / 2; qi++) dacc2[qi] = f32x2{0.0f, 0.0f};
 
-        const float *tsrc[NI];
+        if (!staged0) { // (256 x 256 builds: the previous tile's epilogue has worked these out already -- and staged the first K step)
 #pragma unroll
-        for (int n = 0; n < NI; n++) {
-            if (is_db[n]) {
-                int64_t r = view_row(min(row0 + rloc[n], p.nb - 1), p.row_mul, p.vshift);
-                tsrc[n] = srcp[n] + r * p.dp;
-            } else {
-                tsrc[n] = srcp[n];
+            for (int n = 0; n < NI; n++) {
+                if (is_db[n]) {
+                    int64_t r = view_row(min(row0 + rloc[n], p.nb - 1), p.row_mul, p.vshift);
+                    tsrc[n] = srcp[n] + r * p.dp;
+                } else {
+                    tsrc[n] = srcp[n];
+                }
             }
         }
         if constexpr (L2) {
@@ -1175,9 +1211,24 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
             if (tid < DT) s_yn[tid] = p.yn[view_row(min(row0 + tid, p.nb - 1), p.row_mul, p.vshift)];
         }
         const bool off_diag = SYM && row0 != q0; // (square tiles: the diagonal tile starts at the query tile's first row)
+        // (256 x 256 builds) the queries' thresholds as they stand NOW: an agent-scope load is a round trip to memory, four of
+        // them one after the other were 8 of the epilogue's 10 us; read in front of the K loop they cost nothing, and a bound
+        // one tile old only admits a few candidates more (thresholds only ever tighten)
+        float big_thr[NB];
+        if constexpr (TM * TN >= 16) {
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                const int ql = M16 ? 0 : (wn * TN + b) * 32 + li;
+                big_thr[b] = q0 + ql < p.nq ? L.threshold(ql) : -INFINITY; // (a query past the end admits nothing)
+            }
+        }
         if constexpr (SYM) {
             if (tid < DT) // rows past the end are nobody's query: nothing beats -inf
                 s_thr2[tid] = row0 + tid < p.nb ? ord2f(__hip_atomic_load(&p.gthr[row0 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : -INFINITY;
+            if constexpr (TM * TN >= 16) { // (the sparse epilogue's per-row counters and its "this tile is dense" flag; visible behind the K loop's barriers)
+                if (tid < DT) s_cnt2[tid] = 0;
+                if (tid == 0) L.s_need[2] = 0;
+            }
         }
         // One K step of MFMA work from buffer `cur`.  `dma(n)` (n < NI) issues this wave's n-th
         // staging instruction of the NEXT K step; the NI of them are spread between the MFMAs so
@@ -1404,55 +1455,174 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
         auto no_dma = [](int) {};
         using nd_none = std::integral_constant<int, 0>;
         using nd_all = std::integral_constant<int, NI>;
-        // prologue: stage K step 0 into buffer 0
+        if constexpr (TM * TN >= 16) {
+            // ---- the 256 x 256 tile's K loop: ONE wave per SIMD, so nothing but this wave's own instruction order hides a
+            // latency.  One barrier per K step, in front of the step's LAST sub-step ("late barrier"):
+            //   sub-step 0, 1   MFMAs; the staging instructions of K step kt + 1 (groups A, B) between them
+            //   sub-step 2      MFMAs only -- the staged bytes have a whole sub-step (4096 matrix cycles) to land --, then
+            //                   vmcnt(0) + barrier: stage kt + 1 is in LDS for everyone, and everyone has read stage kt for the
+            //                   last time (the fragments of sub-step 3 were requested at the start of sub-step 2)
+            //   sub-step 3      MFMAs from registers; the FIRST fragments of K step kt + 1 are requested behind the first MFMA
+            //                   (64 MFMAs cover their latency: the next K step starts without a wait), and group C of K step
+            //                   kt + 2 is staged into the buffer stage kt has just left
+            // Every sub-step issues one MFMA, then the fragment reads of the next sub-step: the compiler waits lgkmcnt(0) in front
+            // of a sub-step's first MFMA, and with the reads behind that MFMA the wait only ever covers reads a sub-step old.
+            constexpr int MS = 4 * TM * TN;                        // MFMAs per sub-step
+            constexpr int NA = NI / 3, NBg = NI / 3, NC = NI - NA - NBg; // staging instructions per group
+#ifdef KNN355_TRACE
+            // (developer build: K loop without its staging instructions / its barrier / its fragment reads -- wrong scores, right time)
+            const bool stage_on = !(p.ablate & 16), barrier_on = !(p.ablate & 32), reads_on = !(p.ablate & 128);
+#else
+            constexpr bool stage_on = true, barrier_on = true, reads_on = true;
+#endif
+            f32x4 fa[2][TM], fb[2][TN];
+            auto rd = [&](const char *buf, int t, int set) {
+                if (!reads_on) return;
+                const int slot = ((2 * t + lh) ^ swz) * 16;
 #pragma unroll
-        for (int n = 0; n < NI; n++) {
-            if (NTDB && n < DT / 32) stage_issue<true>(tsrc[n], stage0 + lds_off[n]); // rows, not queries
-            else stage_issue<false>(tsrc[n], stage0 + lds_off[n]);
-        }
-        // Batch launches: the two workgroups of a CU take TURNS in their K loops.  Per-workgroup stamps showed a K loop
-        // running alone (its neighbour in the epilogue) at 94-97 % of the matrix pipe's rate, and two K loops side by side
-        // at 73-84 % together -- every wave's K-step barrier then also waits for the neighbour's waves on the other three
-        // SIMDs.  One word per CU (found through HW_ID / XCC_ID), taken by thread 0 before the K loop and given back behind
-        // it; the neighbour filters its previous tile meanwhile and waits out the rest.  (The word is cleared in front of
-        // every launch; a workgroup alone on its CU never waits.)  Measured: +0.7 % on Pfam-sized launches, +1 % on CATH-sized
-        // ones -- a K loop on its own reaches ~85 % of the pipe as well (one wave per SIMD: nothing fills its barrier bubbles).
-        if constexpr (!NTDB && !BF16) {
-            if (p.cu_turn) {
-                if (tid == 0) {
-                    // (bounded: a turn that never comes -- it cannot, every holder gives the word back behind its K loop -- costs
-                    // a few milliseconds, not the launch)
-                    for (int it = 0; it < 8192; it++) {
-                        if (__hip_atomic_exchange(my_turn, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) break;
-                        __builtin_amdgcn_s_sleep(32);
-                    }
+                for (int a = 0; a < TM; a++) fa[set][a] = *(const f32x4 *)(buf + ((wm * TM + a) * 32 + li) * 128 + slot);
+#pragma unroll
+                for (int b = 0; b < TN; b++) fb[set][b] = *(const f32x4 *)(buf + DT * 128 + ((wn * TN + b) * 32 + li) * 128 + slot);
+            };
+            auto mfmas = [&](int set) {
+#pragma unroll
+                for (int m = 0; m < 4; m++)
+#pragma unroll
+                    for (int a = 0; a < TM; a++)
+#pragma unroll
+                        for (int b = 0; b < TN; b++)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][a][m], fb[set][b][m], acc[a][b], 0, 0, 0);
+            };
+            auto kstep = [&](int kt, auto h1_tag, auto h2_tag) {
+                constexpr bool H1 = decltype(h1_tag)::value, H2 = decltype(h2_tag)::value; // K steps kt + 1 / kt + 2 exist
+                char *cur = (kt & 1) ? stage1 : stage0;
+                char *nxt = (kt & 1) ? stage0 : stage1;
+                const int k1 = (kt + 1) * 32, k2 = (kt + 2) * 32;
+                // sub-step 0 (set 0), fragments of sub-step 1 -> set 1, group A
+                mfmas(0);
+                rd(cur, 1, 1);
+                if constexpr (H1) {
+#pragma unroll
+                    for (int n = 0; n < NA; n++) if (stage_on) stage_issue<false>(tsrc[n] + k1, nxt + lds_off[n]);
                 }
-                // (no barrier of its own: the K loop's first barrier holds the other waves until thread 0 is through)
+                sched_reads<TM + TN>();
+                sched_spread<(H1 ? NA : 0), (MS - (TM + TN)) / (NA + 1)>();
+                __builtin_amdgcn_sched_group_barrier(0x008, MS - (TM + TN) - (H1 ? NA : 0) * ((MS - (TM + TN)) / (NA + 1)), 0);
+                // sub-step 1 (set 1), fragments of sub-step 2 -> set 0, group B
+                mfmas(1);
+                rd(cur, 2, 0);
+                if constexpr (H1) {
+#pragma unroll
+                    for (int n = NA; n < NA + NBg; n++) if (stage_on) stage_issue<false>(tsrc[n] + k1, nxt + lds_off[n]);
+                }
+                sched_reads<TM + TN>();
+                sched_spread<(H1 ? NBg : 0), (MS - (TM + TN)) / (NBg + 1)>();
+                __builtin_amdgcn_sched_group_barrier(0x008, MS - (TM + TN) - (H1 ? NBg : 0) * ((MS - (TM + TN)) / (NBg + 1)), 0);
+                // sub-step 2 (set 0), fragments of sub-step 3 -> set 1, nothing staged; then the K step's one barrier
+                mfmas(0);
+                rd(cur, 3, 1);
+                sched_reads<TM + TN>();
+                __builtin_amdgcn_sched_group_barrier(0x008, MS - (TM + TN), 0);
+                __builtin_amdgcn_sched_barrier(0); // (the wait and the barrier stay BEHIND this sub-step's MFMAs: they are the bytes' time to land)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's part of stage kt + 1 has landed (see the generic loop)
+                if (barrier_on) __syncthreads();
+                // sub-step 3 (set 1), first fragments of K step kt + 1 -> set 0, group C of K step kt + 2 into the buffer just left
+                // (pinned by hand, one fragment read behind each of the first MFMAs and group C in NC pieces between the later ones:
+                // a sched_group_barrier pipeline in the region behind the barrier came out as one burst of NC staging
+                // instructions -- ISA checked)
+                constexpr int PER = MS / (NC + 1);
+                const int slot0 = (lh ^ swz) * 16; // (the first fragments of a K step: 16-byte slot 2 * 0 + lh)
+#pragma unroll
+                for (int i = 0; i < MS; i++) {
+                    const int m = i / (TM * TN), a = (i / TN) % TM, b = i % TN;
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][a][m], fb[1][b][m], acc[a][b], 0, 0, 0);
+                    bool pinned = false;
+                    if (H1 && i < TM + TN && reads_on) { // one fragment read behind each of the first MFMAs
+                        if (i < TM) fa[0][i] = *(const f32x4 *)(nxt + ((wm * TM + i) * 32 + li) * 128 + slot0);
+                        else fb[0][i - TM] = *(const f32x4 *)(nxt + DT * 128 + ((wn * TN + (i - TM)) * 32 + li) * 128 + slot0);
+                        pinned = true;
+                    }
+                    if (H2 && (i + 1) % PER == 0 && (i + 1) / PER <= NC) {
+                        const int n = NA + NBg + (i + 1) / PER - 1;
+                        if (stage_on) stage_issue<false>(tsrc[n] + k2, cur + lds_off[n]);
+                        pinned = true;
+                    }
+                    if (pinned) __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            // prologue: stage K step 0, wait, barrier; group C of K step 1; the first fragments (the one exposed read of the tile)
+            if (!staged0) {
+#pragma unroll
+                for (int n = 0; n < NI; n++) stage_issue<false>(tsrc[n], stage0 + lds_off[n]);
             }
-        }
-        for (int kt = 0; kt + 1 < KT; kt++) {
-            char *cur = (kt & 1) ? stage1 : stage0;
-            char *nxt = (kt & 1) ? stage0 : stage1;
-            diff_koff = kt * 32;
-            // Stage kt has landed in LDS for EVERY wave's reads: this wave's staging instructions are waited for HERE,
-            // explicitly, then the barrier.  (Nothing else orders a ds_read behind a pending LDS-DMA: until round 4 the wait
-            // was the compiler's -- it puts a vmcnt(0) in front of LDS reads it cannot tell apart from a pending DMA's target
-            // -- and one instantiation lost it when the address arithmetic of the staging instructions changed: wrong scores
-            // from the third K step on.  Inline asm: the waitcnt pass cannot drop it.)
+            staged0 = false;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads(); // buffer nxt is free
-            const int koff = (kt + 1) * 32;
-            compute(cur, [&](int n) {
-                if (NTDB && n < DT / 32) stage_issue<true>(tsrc[n] + koff, nxt + lds_off[n]);
-                else stage_issue<false>(tsrc[n] + koff, nxt + lds_off[n]);
-            }, nd_all{});
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (see above)
-        __syncthreads();
-        diff_koff = (KT - 1) * 32;
-        compute(((KT - 1) & 1) ? stage1 : stage0, no_dma, nd_none{});
-        if constexpr (!NTDB && !BF16) {
-            if (p.cu_turn && tid == 0) __hip_atomic_store(my_turn, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (KT > 1) {
+#pragma unroll
+                for (int n = NA + NBg; n < NI; n++) stage_issue<false>(tsrc[n] + 32, stage1 + lds_off[n]);
+            }
+            rd(stage0, 0, 0);
+            using yes = std::true_type;
+            using no = std::false_type;
+            int kt = 0;
+            for (; kt + 2 < KT; kt++) kstep(kt, yes{}, yes{});
+            if (kt + 1 < KT) {
+                kstep(kt, yes{}, no{});
+                kt++;
+            }
+            kstep(kt, no{}, no{});
+        } else {
+            // prologue: stage K step 0 into buffer 0
+#pragma unroll
+            for (int n = 0; n < NI; n++) {
+                if (NTDB && n < DT / 32) stage_issue<true>(tsrc[n], stage0 + lds_off[n]); // rows, not queries
+                else stage_issue<false>(tsrc[n], stage0 + lds_off[n]);
+            }
+            // Batch launches: the two workgroups of a CU take TURNS in their K loops.  Per-workgroup stamps showed a K loop
+            // running alone (its neighbour in the epilogue) at 94-97 % of the matrix pipe's rate, and two K loops side by side
+            // at 73-84 % together -- every wave's K-step barrier then also waits for the neighbour's waves on the other three
+            // SIMDs.  One word per CU (found through HW_ID / XCC_ID), taken by thread 0 before the K loop and given back behind
+            // it; the neighbour filters its previous tile meanwhile and waits out the rest.  (The word is cleared in front of
+            // every launch; a workgroup alone on its CU never waits.)  Measured: +0.7 % on Pfam-sized launches, +1 % on CATH-sized
+            // ones -- a K loop on its own reaches ~85 % of the pipe as well (one wave per SIMD: nothing fills its barrier bubbles).
+            if constexpr (!NTDB && !BF16) {
+                if (p.cu_turn) {
+                    if (tid == 0) {
+                        // (bounded: a turn that never comes -- it cannot, every holder gives the word back behind its K loop -- costs
+                        // a few milliseconds, not the launch)
+                        for (int it = 0; it < 8192; it++) {
+                            if (__hip_atomic_exchange(my_turn, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) break;
+                            __builtin_amdgcn_s_sleep(32);
+                        }
+                    }
+                    // (no barrier of its own: the K loop's first barrier holds the other waves until thread 0 is through)
+                }
+            }
+            for (int kt = 0; kt + 1 < KT; kt++) {
+                char *cur = (kt & 1) ? stage1 : stage0;
+                char *nxt = (kt & 1) ? stage0 : stage1;
+                diff_koff = kt * 32;
+                // Stage kt has landed in LDS for EVERY wave's reads: this wave's staging instructions are waited for HERE,
+                // explicitly, then the barrier.  (Nothing else orders a ds_read behind a pending LDS-DMA: until round 4 the wait
+                // was the compiler's -- it puts a vmcnt(0) in front of LDS reads it cannot tell apart from a pending DMA's target
+                // -- and one instantiation lost it when the address arithmetic of the staging instructions changed: wrong scores
+                // from the third K step on.  Inline asm: the waitcnt pass cannot drop it.)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads(); // buffer nxt is free
+                const int koff = (kt + 1) * 32;
+                compute(cur, [&](int n) {
+                    if (NTDB && n < DT / 32) stage_issue<true>(tsrc[n] + koff, nxt + lds_off[n]);
+                    else stage_issue<false>(tsrc[n] + koff, nxt + lds_off[n]);
+                }, nd_all{});
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (see above)
+            __syncthreads();
+            diff_koff = (KT - 1) * 32;
+            compute(((KT - 1) & 1) ? stage1 : stage0, no_dma, nd_none{});
+            if constexpr (!NTDB && !BF16) {
+                if (p.cu_turn && tid == 0) __hip_atomic_store(my_turn, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         if constexpr (DIFF) {
             // the scores change hands: from "thread = row, register = query" to the accumulator layout the MFMA leaves behind
@@ -1641,6 +1811,286 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
             }
         }
 
+        // ---- the 256 x 256 tile's epilogue ("sparse"): ONE workgroup per CU, so nothing runs beside it -- what filter_tile
+        // spends per tile (60-120 us of a 240 us K loop, measured: nearly every block of 8 scores has a survivor in SOME lane,
+        // and the wave then walks eight divergent appends) is all exposed.  A lane's 256 scores hold one to three survivors at
+        // the densities a warmed-up or seeded threshold leaves (0.3-1.5 %), at random places, and registers cannot be indexed
+        // by a lane-varying number.  So:
+        //   pass 1  straight-line, eight vector instructions per score (inline asm: left to the compiler the accumulators were
+        //           copied out of their AGPRs wholesale and spilled): value, ONE compare, a store of (value, score number) into
+        //           the lane's next slot of the (idle) staging buffers -- [slot][thread] x 8 bytes -- by EVERY lane, and a
+        //           pointer bump where the compare passed (a failed score's entry is overwritten by the lane's next survivor;
+        //           first form, with the store under the compare's exec mask: 11.6 us per tile, the wave waiting on every
+        //           vector-to-scalar hand-over); a lane that runs out of slots writes into a dump slot and keeps counting;
+        //   pass 2  a wave-wide loop over the slots in use (as many rounds as the busiest lane has survivors): each lane reads
+        //           its entry back, works out row and key, reserves a place in the query's list (LDS atomic) and stores.
+        // A wave with a lane that ran out of slots (the first tiles of an unseeded chunk, tiles full of near-duplicates) filters
+        // the tile the dense way instead.  The symmetric launch's second direction (row R of this tile as a query, the resident
+        // tile's rows its candidates) goes the same way with a second compare per score; its survivors are ranked per row in
+        // LDS (the atomic's return), one global atomic per row reserves the places, then the keys are stored; a lane out of
+        // slots hands the whole tile's second direction to the dense code below.
+        bool dir2_dense = SYM && off_diag; // the second direction is (still) the dense code's
+        auto sparse_epilogue = [&](int64_t trow0, bool second, auto *dense2) { // (generic: only the 256 x 256 builds instantiate it)
+            // slots per lane and tile, first / second direction (+ a dump slot each), all inside staging buffer 1: buffer 0 is
+            // taking the next tile's first K step meanwhile
+            constexpr int C1 = SYM ? 24 : 31, C2 = SYM ? 6 : 0;
+            constexpr int OFF1 = STAGE_BYTES, OFF2 = OFF1 + (C1 + 1) * 2048; // the second direction's slots start behind the first's
+            static_assert(OFF2 + (SYM ? (C2 + 1) * 2048 : 0) <= 2 * STAGE_BYTES, "the lanes' slots fit staging buffer 1");
+            static_assert(NS == 64 && NB == 4, "score numbers are sc | block << 8");
+            const bool ragged = trow0 + DT > p.nb, sampled = p.skip_mask >= 0, plain_rows = p.row_mul == 1;
+            const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)smem);
+            int *s_dense = L.s_need + 2;
+            const float *thr = big_thr, *xnq = big_xnq;
+            const uint64_t *cokm = big_cokm;
+            KNN_TRACE_AT(tile_idx == 5, 124);
+            const uint32_t w1_0 = lds0 + OFF1 + tid * 8, w2_0 = lds0 + OFF2 + tid * 8;
+            uint32_t w1 = w1_0, w2 = w2_0;                          // LDS address of this lane's next slot (counts on past the last)
+            const uint32_t dump1 = w1_0 + C1 * 2048, dump2 = w2_0 + C2 * 2048;
+            const uint32_t step = 2048;
+            const float ninf = -INFINITY;
+            KNN_TRACE_AT(tile_idx == 5, 125);
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");       // (the K loop's last MFMAs -> v_accvgpr_read inside the statements below)
+            // (one body per case, chosen once: with `second` tested inside, the compiler put a branch and a handful of spills
+            // around every statement of the symmetric builds)
+            uint32_t nblk[NB] = {}; // first direction: 2048 x this lane's survivors of each query block
+            auto pass1 = [&](auto second_tag) {
+                (void)&w2; (void)&ninf; (void)&dump2; (void)&cokm; // (named here: captures that only a discarded branch uses are not made)
+                // four scores per statement: their value / compare chains are independent and issue back to back (one wave per SIMD:
+                // a chain on its own waits out every instruction's latency), only the pointer bumps are serial
+#pragma unroll
+                for (int c = 0; c < NS; c += 16) {
+                    // the norms / second-direction thresholds of this chunk's 16 rows: four consecutive rows per 16-byte LDS read
+                    // (all 64 rows of the tile at once cost 128 registers in the symmetric L2 build: spills between the statements)
+                    float ynl[16], t2l[16];
+#pragma unroll
+                    for (int i = 0; i < 16; i += 4) {
+                        f32x4 y4 = {0.0f, 0.0f, 0.0f, 0.0f}, h4 = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                        if constexpr (L2) y4 = *(const f32x4 *)&s_yn[rowl(c + i)];
+                        if constexpr (SYM) h4 = *(const f32x4 *)&s_thr2[rowl(c + i)];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            ynl[i + e] = y4[e];
+                            t2l[i + e] = h4[e];
+                        }
+                    }
+#pragma unroll
+                    for (int b = 0; b < NB; b++) {
+                    const uint32_t w1_b = w1; // (this lane's survivors of query block b: what the 16 scores below add to the pointer)
+#pragma unroll
+                    for (int sc = c; sc < c + 16; sc += 4) {
+                        uint32_t t[4], ad[4], ix[4], u;
+                        uint64_t mk[4];
+                        const float a0 = accv(b, sc), a1 = accv(b, sc + 1), a2 = accv(b, sc + 2), a3 = accv(b, sc + 3);
+                        if constexpr (L2) {
+                            const float s0 = xnq[b] + ynl[sc - c], s1 = xnq[b] + ynl[sc - c + 1], s2 = xnq[b] + ynl[sc - c + 2], s3 = xnq[b] + ynl[sc - c + 3];
+                            asm volatile("v_accvgpr_read_b32 %[t0], %[a0]\n\t"
+                                         "v_accvgpr_read_b32 %[t1], %[a1]\n\t"
+                                         "v_accvgpr_read_b32 %[t2], %[a2]\n\t"
+                                         "v_accvgpr_read_b32 %[t3], %[a3]\n\t"
+                                         "v_fma_f32 %[t0], %[t0], -2.0, %[s0]\n\t"
+                                         "v_fma_f32 %[t1], %[t1], -2.0, %[s1]\n\t"
+                                         "v_fma_f32 %[t2], %[t2], -2.0, %[s2]\n\t"
+                                         "v_fma_f32 %[t3], %[t3], -2.0, %[s3]\n\t"
+                                         "v_cmp_le_f32_e64 %[m0], %[t0], %[thr]\n\t"
+                                         "v_cmp_le_f32_e64 %[m1], %[t1], %[thr]\n\t"
+                                         "v_cmp_le_f32_e64 %[m2], %[t2], %[thr]\n\t"
+                                         "v_cmp_le_f32_e64 %[m3], %[t3], %[thr]\n\t"
+                                         "v_min_u32_e32 %[ad0], %[w], %[dump]\n\t"
+                                         "v_cndmask_b32_e64 %[u], 0, %[step], %[m0]\n\t"
+                                         "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                         "v_min_u32_e32 %[ad1], %[w], %[dump]\n\t"
+                                         "v_cndmask_b32_e64 %[u], 0, %[step], %[m1]\n\t"
+                                         "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                         "v_min_u32_e32 %[ad2], %[w], %[dump]\n\t"
+                                         "v_cndmask_b32_e64 %[u], 0, %[step], %[m2]\n\t"
+                                         "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                         "v_min_u32_e32 %[ad3], %[w], %[dump]\n\t"
+                                         "v_cndmask_b32_e64 %[u], 0, %[step], %[m3]\n\t"
+                                         "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                         "v_mov_b32_e32 %[i0], %[idx0]\n\t"
+                                         "v_mov_b32_e32 %[i1], %[idx1]\n\t"
+                                         "v_mov_b32_e32 %[i2], %[idx2]\n\t"
+                                         "v_mov_b32_e32 %[i3], %[idx3]\n\t"
+                                         "ds_write2_b32 %[ad0], %[t0], %[i0] offset1:1\n\t"
+                                         "ds_write2_b32 %[ad1], %[t1], %[i1] offset1:1\n\t"
+                                         "ds_write2_b32 %[ad2], %[t2], %[i2] offset1:1\n\t"
+                                         "ds_write2_b32 %[ad3], %[t3], %[i3] offset1:1"
+                                         : [t0] "=&v"(t[0]), [t1] "=&v"(t[1]), [t2] "=&v"(t[2]), [t3] "=&v"(t[3]), [ad0] "=&v"(ad[0]), [ad1] "=&v"(ad[1]), [ad2] "=&v"(ad[2]), [ad3] "=&v"(ad[3]), [i0] "=&v"(ix[0]), [i1] "=&v"(ix[1]), [i2] "=&v"(ix[2]), [i3] "=&v"(ix[3]), [m0] "=&s"(mk[0]), [m1] "=&s"(mk[1]), [m2] "=&s"(mk[2]), [m3] "=&s"(mk[3]), [u] "=&v"(u), [w] "+v"(w1)
+                                         : [a0] "a"(a0), [a1] "a"(a1), [a2] "a"(a2), [a3] "a"(a3), [s0] "v"(s0), [s1] "v"(s1), [s2] "v"(s2), [s3] "v"(s3),
+                                           [thr] "v"(thr[b]), [dump] "v"(dump1), [step] "v"(step), [idx0] "n"((sc + 0) | (b << 8)), [idx1] "n"((sc + 1) | (b << 8)), [idx2] "n"((sc + 2) | (b << 8)), [idx3] "n"((sc + 3) | (b << 8))
+                                         : "memory");
+                        } else {
+                            asm volatile("v_accvgpr_read_b32 %[t0], %[a0]\n\t"
+                                         "v_accvgpr_read_b32 %[t1], %[a1]\n\t"
+                                         "v_accvgpr_read_b32 %[t2], %[a2]\n\t"
+                                         "v_accvgpr_read_b32 %[t3], %[a3]\n\t"
+                                         "v_xor_b32_e32 %[t0], 0x80000000, %[t0]\n\t"
+                                         "v_xor_b32_e32 %[t1], 0x80000000, %[t1]\n\t"
+                                         "v_xor_b32_e32 %[t2], 0x80000000, %[t2]\n\t"
+                                         "v_xor_b32_e32 %[t3], 0x80000000, %[t3]\n\t"
+                                         "v_cmp_le_f32_e64 %[m0], %[t0], %[thr]\n\t"
+                                         "v_cmp_le_f32_e64 %[m1], %[t1], %[thr]\n\t"
+                                         "v_cmp_le_f32_e64 %[m2], %[t2], %[thr]\n\t"
+                                         "v_cmp_le_f32_e64 %[m3], %[t3], %[thr]\n\t"
+                                         "v_min_u32_e32 %[ad0], %[w], %[dump]\n\t"
+                                         "v_cndmask_b32_e64 %[u], 0, %[step], %[m0]\n\t"
+                                         "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                         "v_min_u32_e32 %[ad1], %[w], %[dump]\n\t"
+                                         "v_cndmask_b32_e64 %[u], 0, %[step], %[m1]\n\t"
+                                         "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                         "v_min_u32_e32 %[ad2], %[w], %[dump]\n\t"
+                                         "v_cndmask_b32_e64 %[u], 0, %[step], %[m2]\n\t"
+                                         "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                         "v_min_u32_e32 %[ad3], %[w], %[dump]\n\t"
+                                         "v_cndmask_b32_e64 %[u], 0, %[step], %[m3]\n\t"
+                                         "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                         "v_mov_b32_e32 %[i0], %[idx0]\n\t"
+                                         "v_mov_b32_e32 %[i1], %[idx1]\n\t"
+                                         "v_mov_b32_e32 %[i2], %[idx2]\n\t"
+                                         "v_mov_b32_e32 %[i3], %[idx3]\n\t"
+                                         "ds_write2_b32 %[ad0], %[t0], %[i0] offset1:1\n\t"
+                                         "ds_write2_b32 %[ad1], %[t1], %[i1] offset1:1\n\t"
+                                         "ds_write2_b32 %[ad2], %[t2], %[i2] offset1:1\n\t"
+                                         "ds_write2_b32 %[ad3], %[t3], %[i3] offset1:1"
+                                         : [t0] "=&v"(t[0]), [t1] "=&v"(t[1]), [t2] "=&v"(t[2]), [t3] "=&v"(t[3]), [ad0] "=&v"(ad[0]), [ad1] "=&v"(ad[1]), [ad2] "=&v"(ad[2]), [ad3] "=&v"(ad[3]), [i0] "=&v"(ix[0]), [i1] "=&v"(ix[1]), [i2] "=&v"(ix[2]), [i3] "=&v"(ix[3]), [m0] "=&s"(mk[0]), [m1] "=&s"(mk[1]), [m2] "=&s"(mk[2]), [m3] "=&s"(mk[3]), [u] "=&v"(u), [w] "+v"(w1)
+                                         : [a0] "a"(a0), [a1] "a"(a1), [a2] "a"(a2), [a3] "a"(a3),
+                                           [thr] "v"(thr[b]), [dump] "v"(dump1), [step] "v"(step), [idx0] "n"((sc + 0) | (b << 8)), [idx1] "n"((sc + 1) | (b << 8)), [idx2] "n"((sc + 2) | (b << 8)), [idx3] "n"((sc + 3) | (b << 8))
+                                         : "memory");
+                        }
+                        if constexpr (SYM) {
+                            if constexpr (decltype(second_tag)::value) { // (workgroup-uniform) the same values decide for rows rowl(sc ..) as queries; a lane whose own query
+                                          // is no candidate -- past the end, or a row of the sample -- compares against -inf
+                                uint32_t e[4];
+                                asm volatile("v_cndmask_b32_e64 %[e0], %[ninf], %[h0], %[cok]\n\t"
+                                             "v_cndmask_b32_e64 %[e1], %[ninf], %[h1], %[cok]\n\t"
+                                             "v_cndmask_b32_e64 %[e2], %[ninf], %[h2], %[cok]\n\t"
+                                             "v_cndmask_b32_e64 %[e3], %[ninf], %[h3], %[cok]\n\t"
+                                             "v_cmp_le_f32_e64 %[m0], %[t0], %[e0]\n\t"
+                                             "v_cmp_le_f32_e64 %[m1], %[t1], %[e1]\n\t"
+                                             "v_cmp_le_f32_e64 %[m2], %[t2], %[e2]\n\t"
+                                             "v_cmp_le_f32_e64 %[m3], %[t3], %[e3]\n\t"
+                                             "v_min_u32_e32 %[ad0], %[w], %[dump]\n\t"
+                                             "v_cndmask_b32_e64 %[u], 0, %[step], %[m0]\n\t"
+                                             "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                             "v_min_u32_e32 %[ad1], %[w], %[dump]\n\t"
+                                             "v_cndmask_b32_e64 %[u], 0, %[step], %[m1]\n\t"
+                                             "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                             "v_min_u32_e32 %[ad2], %[w], %[dump]\n\t"
+                                             "v_cndmask_b32_e64 %[u], 0, %[step], %[m2]\n\t"
+                                             "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                             "v_min_u32_e32 %[ad3], %[w], %[dump]\n\t"
+                                             "v_cndmask_b32_e64 %[u], 0, %[step], %[m3]\n\t"
+                                             "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                             "v_mov_b32_e32 %[i0], %[idx0]\n\t"
+                                             "v_mov_b32_e32 %[i1], %[idx1]\n\t"
+                                             "v_mov_b32_e32 %[i2], %[idx2]\n\t"
+                                             "v_mov_b32_e32 %[i3], %[idx3]\n\t"
+                                             "ds_write2_b32 %[ad0], %[t0], %[i0] offset1:1\n\t"
+                                             "ds_write2_b32 %[ad1], %[t1], %[i1] offset1:1\n\t"
+                                             "ds_write2_b32 %[ad2], %[t2], %[i2] offset1:1\n\t"
+                                             "ds_write2_b32 %[ad3], %[t3], %[i3] offset1:1"
+                                             : [e0] "=&v"(e[0]), [e1] "=&v"(e[1]), [e2] "=&v"(e[2]), [e3] "=&v"(e[3]), [ad0] "=&v"(ad[0]), [ad1] "=&v"(ad[1]), [ad2] "=&v"(ad[2]), [ad3] "=&v"(ad[3]), [i0] "=&v"(ix[0]), [i1] "=&v"(ix[1]), [i2] "=&v"(ix[2]), [i3] "=&v"(ix[3]), [m0] "=&s"(mk[0]), [m1] "=&s"(mk[1]), [m2] "=&s"(mk[2]), [m3] "=&s"(mk[3]), [u] "=&v"(u), [w] "+v"(w2)
+                                             : [t0] "v"(t[0]), [t1] "v"(t[1]), [t2] "v"(t[2]), [t3] "v"(t[3]),
+                                               [h0] "v"(t2l[sc - c]), [h1] "v"(t2l[sc - c + 1]), [h2] "v"(t2l[sc - c + 2]), [h3] "v"(t2l[sc - c + 3]),
+                                               [ninf] "v"(ninf), [cok] "s"(cokm[b]), [dump] "v"(dump2), [step] "v"(step), [idx0] "n"((sc + 0) | (b << 8)), [idx1] "n"((sc + 1) | (b << 8)), [idx2] "n"((sc + 2) | (b << 8)), [idx3] "n"((sc + 3) | (b << 8))
+                                             : "memory");
+                            }
+                        }
+                    }
+                    nblk[b] += w1 - w1_b;
+                }
+                }
+            };
+            if (SYM && second) pass1(std::true_type{});
+            else pass1(std::false_type{});
+            KNN_TRACE_AT(tile_idx == 5, 126);
+            const int n1 = (int)((w1 - w1_0) >> 11), n2 = (int)((w2 - w2_0) >> 11);
+            // ---- first direction: this wave's survivors -> the queries' lists
+            if (__ballot(n1 > C1) != 0ull) {
+                filter_tile(trow0, passes_acc, score_of); // (a lane ran out of slots: the dense way, from the accumulators)
+            } else {
+                // One reservation per lane and query block -- four LDS atomics, in flight together -- then the entries four per
+                // round: LDS reads and stores only.  (One atomic per entry and one entry per round: 4.8 us per tile at k = 100, 12.4
+                // at k = 1000, each round a chain of three dependent round trips; four entries per round: 2.9 / 7.6.)
+                bool near_full = false;
+                int base[NB], run[NB];
+#pragma unroll
+                for (int b = 0; b < NB; b++) {
+                    const int cnt = (int)(nblk[b] >> 11);
+                    base[b] = atomicAdd(&L.s_cnt[qloc(b)], cnt);
+                    run[b] = 0;
+                    near_full |= cnt > 0 && base[b] + cnt > L.cap - DT;
+                }
+                for (int j0 = 0; __ballot(j0 < n1) != 0ull; j0 += 4) {
+                    uint2 e[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) e[u] = *(const uint2 *)(smem + OFF1 + (min(j0 + u, C1) * 256 + tid) * 8);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (j0 + u < n1) {
+                            const int b = (int)((e[u].y >> 8) & 3u);
+                            // (b is a runtime number: the block's base and running count picked out of four registers each)
+                            const int slot = (b == 0 ? base[0] + run[0] : b == 1 ? base[1] + run[1] : b == 2 ? base[2] + run[2] : base[3] + run[3]);
+                            run[0] += b == 0; run[1] += b == 1; run[2] += b == 2; run[3] += b == 3;
+                            const int ql = (wn * TN + b) * 32 + li;
+                            float vv = __uint_as_float(e[u].x);
+                            if constexpr (L2) vv = vv < 0.0f ? 0.0f : vv;
+                            vv += 0.0f;
+                            const int64_t row = trow0 + rowl((int)(e[u].y & 255u));
+                            const uint32_t id = p.id_base + (plain_rows ? (uint32_t)row : (uint32_t)view_row(row, p.row_mul, p.vshift));
+                            const bool gone = (ragged && row >= p.nb) || (sampled && ((int)(row >> p.vshift) & p.skip_mask) == 0);
+                            if (slot < L.cap) L.lists[(size_t)ql * L.cap + slot] = gone ? KEY_PAD : (((uint64_t)f2ord(vv) << 32) | id);
+                        }
+                    }
+                }
+                if (near_full) *L.s_need = 1;
+            }
+            KNN_TRACE_AT(tile_idx == 5, 127);
+            // ---- second direction (symmetric launch, off the diagonal): the rows of this tile as queries
+            if constexpr (SYM) {
+                if (!second) return; // (workgroup-uniform: the diagonal tile)
+                if (n2 > C2) *s_dense = 1;
+                __syncthreads();
+                const bool dense = *s_dense != 0;
+                *dense2 = dense;
+                if (dense) return; // (the flag is cleared at the start of the next tile)
+                // ranks inside each row's survivors of this tile
+                for (int j0 = 0; j0 < n2; j0 += 4) { // (four reservations in flight)
+                    uint32_t *yp[4], y[4];
+                    int rk[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        yp[u] = (uint32_t *)(smem + OFF2 + (min(j0 + u, C2) * 256 + tid) * 8 + 4);
+                        y[u] = *yp[u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) rk[u] = atomicAdd(&s_cnt2[rowl((int)(y[u] & 63u))], j0 + u < n2 ? 1 : 0);
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (j0 + u < n2) *yp[u] = y[u] | ((unsigned)rk[u] << 16);
+                }
+                __syncthreads();
+                if (tid < DT) {
+                    const int c = s_cnt2[tid];
+                    s_base2[tid] = c > 0 ? (int)atomicAdd(&p.qcnt[trow0 + tid], (uint32_t)c) : 0;
+                    s_cnt2[tid] = 0; // (for the next tile)
+                }
+                __syncthreads();
+                for (int j = 0; j < n2; j++) {
+                    const uint2 e = *(const uint2 *)(smem + OFF2 + (j * 256 + tid) * 8);
+                    const int sc = (int)(e.y & 255u), b = (int)((e.y >> 8) & 255u), rank = (int)(e.y >> 16);
+                    const int rl = rowl(sc);
+                    float vv = __uint_as_float(e.x);
+                    if constexpr (L2) vv = vv < 0.0f ? 0.0f : vv;
+                    const int at = s_base2[rl] + rank;
+                    // (b is a runtime number here: the lane's query of block b, spelled out)
+                    const uint32_t id = p.id_base + (uint32_t)(q0 + (wn * TN + b) * 32 + li);
+                    if (at < p.qcap) p.qlist[(size_t)(trow0 + rl) * p.qcap + at] = ((uint64_t)f2ord(vv + 0.0f) << 32) | id;
+                    else *p.fail = 1;
+                }
+            }
+        };
+
         // ---- epilogue: threshold filter + append ----
 #ifdef KNN355_TRACE
         if (p.ablate & 4) { // all MFMA results of this wave have landed before the "K loop ended" stamp is taken
@@ -1652,7 +2102,24 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
         }
         if (!(p.ablate & 1))
 #endif
-        if (!deferred) filter_tile(row0, passes_acc, score_of);
+        {
+            if constexpr (TM * TN >= 16) {
+                // The next tile's first K step goes out NOW, into buffer 0: behind the K loop's last barrier no wave reads a
+                // staging buffer any more (the last sub-step runs from registers), the epilogue below keeps its slots in
+                // buffer 1, and its ~8 us cover the bytes' way from L2 / HBM -- the tile prologue found them exposed (2-3 us
+                // per tile with nothing else on the CU).
+                if (next_tile >= 0) {
+                    const int64_t nrow0 = (int64_t)next_tile * DT;
+#pragma unroll
+                    for (int n = 0; n < NI; n++) {
+                        tsrc[n] = is_db[n] ? srcp[n] + view_row(min(nrow0 + rloc[n], p.nb - 1), p.row_mul, p.vshift) * p.dp : srcp[n];
+                        stage_issue<false>(tsrc[n], stage0 + lds_off[n]);
+                    }
+                    staged0 = true;
+                }
+                sparse_epilogue(row0, off_diag, &dir2_dense);
+            } else if (!deferred) filter_tile(row0, passes_acc, score_of);
+        }
         KNN_TRACE(64 + 2 * tile_idx);
         if constexpr (CAN_PUB) {
             if (pub_on && (tile_idx == 1 || (deferred && (paired ? *s_next : next_tile) < 0))) {
@@ -1671,9 +2138,9 @@ __global__ __launch_bounds__(256, 2) void flat_scan_kernel(ScanParams p)
         }
         if constexpr (SYM) {
 #ifdef KNN355_TRACE
-            if (off_diag && !(p.ablate & 8)) {
+            if (dir2_dense && !(p.ablate & 8)) {
 #else
-            if (off_diag) {
+            if (dir2_dense) {
 #endif
                 // the same scores, read the other way round: row R of this tile is a query, the resident tile's rows
                 // are its candidates.  A (register, lane half) pair of one wave is one row R and 32 candidates.
@@ -2360,6 +2827,7 @@ struct knn_index_s {
     DevBuf ws_flag;               // [0]: a statistically seeded search failed its verification
     DevBuf ws_sym;                // work table of a symmetric all-vs-all launch
     int sym_tiles = -1, sym_run = 0; // ... which is the table for this many tiles (run length sym_run, sym_items entries)
+    int sym_ts = 0;               // ... of this many rows each
     int64_t sym_items = 0;
     int sym_groups = 1;           // ... in this many groups of query tiles, one launch each (results streamed to the host group by group)
     std::vector<int64_t> sym_gstart; // [sym_groups + 1] first entry of each group
@@ -2939,6 +3407,17 @@ static int launch_scan_cfg(const knn_index_s *h, const ScanParams &p, const Scan
     return 0;
 }
 
+// the 256 x 256 tile (2 x 2 waves of 4 x 4 MFMA tiles, one workgroup per CU): plain fp32 rows, several query tiles per launch
+static int launch_scan_big(const knn_index_s *h, const ScanParams &p, const ScanPlan &plan, hipStream_t s)
+{
+    if (h->approx16) return set_err(KNN_ERR_INVALID, "scan: the 256-query tile serves plain fp32 rows");
+    void (*kern)(ScanParams) = h->metric == KNN_METRIC_L2 ? flat_scan_kernel<2, 2, 4, 4, true, false> : flat_scan_kernel<2, 2, 4, 4, false, false>;
+    HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds));
+    hipLaunchKernelGGL(kern, dim3(plan.grid), dim3(256), plan.lds, s, p);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // the builds on 16-query blocks (48 queries: 4 x 1 waves, 96: 2 x 2 waves; Q16 blocks per wave): one query tile per launch
 template <int WM, int WN, int TM, int Q16>
 static int launch_scan16(const knn_index_s *h, const ScanParams &p, const ScanPlan &plan, hipStream_t s)
@@ -2952,17 +3431,33 @@ static int launch_scan16(const knn_index_s *h, const ScanParams &p, const ScanPl
     return 0;
 }
 
-static void make_plan(const knn_index_s *h, int64_t nb, int64_t nq, int k, bool seeded, ScanPlan &pl, bool allow_pairs = false)
+// Does the 256 x 256 tile (flat_scan_kernel<2, 2, 4, 4>: one workgroup per CU) serve this search?  Its K loop keeps the matrix
+// pipe busier than two co-resident 128 x 128 workgroups do, but nothing hides its epilogues, a launch has half the
+// workgroups and four times the tile: it wants long chunks on every CU -- Pfam-sized batches, not CATH-sized ones.
+// flags & 262144: never; flags & 524288: wherever a batch has more than 128 queries (tests, A/B).
+static bool big_tile_pays(const knn_index_s *h, int64_t nb, int64_t nq)
+{
+    if (h->approx16 || (h->flags & 262144) || nq <= 128) return false;
+    if (h->flags & 524288) return nb >= 1024;
+    if (nb < 65536) return false; // (never a seed sample's own scan)
+    const int64_t cus = std::max(1, h->num_cus);
+    const int64_t work = ((nq + 255) / 256) * ((nb + 255) / 256); // 256 x 256 tiles of the search
+    return nq >= dev_knob("KNN355_BIG_MIN_NQ", 2048) && work >= (int64_t)dev_knob("KNN355_BIG_MIN_TILES_PER_CU", 32) * cus;
+}
+
+static void make_plan(const knn_index_s *h, int64_t nb, int64_t nq, int k, bool seeded, ScanPlan &pl, bool allow_pairs = false, bool allow_big = true)
 {
     int qt = h->force_qt;
     // (48 and 96: the 16-query-block builds, one query tile per launch only -- a forced one is honoured if it holds the batch)
     if ((qt == 48 || qt == 96) && (nq > qt || h->approx16)) qt = 0;
-    if (qt != 32 && qt != 48 && qt != 64 && qt != 96 && qt != 128) {
+    if (qt == 256 && (h->approx16 || nq <= 128)) qt = 0; // (the 256 x 256 tile: plain fp32 rows, more than one 128-query tile of queries)
+    if (qt != 32 && qt != 48 && qt != 64 && qt != 96 && qt != 128 && qt != 256) {
         qt = nq <= 32 ? 32 : (nq <= 64 ? 64 : 128);
         if (!h->approx16 && !(h->flags & 131072)) { // (flags & 131072: without the 16-query-block builds)
             if (nq > 32 && nq <= 48) qt = 48;
             else if (nq > 64 && nq <= 96) qt = 96;
         }
+        if (allow_big && big_tile_pays(h, nb, nq)) qt = 256;
     }
     // FAISS's squared L2 for fewer than 20 queries: the sum of squared differences (flags & 32: the norm formula throughout).
     // FAISS decides on the batch its caller handed over, so a piece of a larger batch (the last block of 16384 queries, the
@@ -2970,13 +3465,16 @@ static void make_plan(const knn_index_s *h, int64_t nb, int64_t nq, int k, bool 
     const bool small_batch = (h->batch_nq ? h->batch_nq : nq) < 20 && nq < 20;
     if (h->metric == KNN_METRIC_L2 && small_batch && !h->approx16 && !(h->flags & 32)) qt = 32; // (the difference build exists for the 32-query tile only)
     pl.qt = qt;
-    pl.dt = (qt == 32 || qt == 48) ? 256 : 128;
+    pl.dt = (qt == 32 || qt == 48 || qt == 256) ? 256 : 128;
     pl.diff = h->metric == KNN_METRIC_L2 && small_batch && qt == 32 && !h->approx16 && !(h->flags & 32);
     pl.name = pl.diff ? "flat_scan_q32_d256_l2diff"
-                      : (qt == 128 ? "flat_scan_q128_d128" : (qt == 96 ? "flat_scan_q96_d128" : (qt == 64 ? "flat_scan_q64_d128" : (qt == 48 ? "flat_scan_q48_d256" : "flat_scan_q32_d256"))));
+                      : (qt == 256 ? "flat_scan_q256_d256" : qt == 128 ? "flat_scan_q128_d128" : (qt == 96 ? "flat_scan_q96_d128" : (qt == 64 ? "flat_scan_q64_d128" : (qt == 48 ? "flat_scan_q48_d256" : "flat_scan_q32_d256"))));
     pl.nqtiles = (int)((nq + qt - 1) / qt);
     pl.cap = next_pow2_host(2 * k + pl.dt);
     if (pl.cap < 512) pl.cap = 512;
+    // (the 256 x 256 tile: nothing hides a cut of its 256 lists on four waves -- 220 us, a K loop's worth: room for three tiles
+    // of appends between cuts)
+    if (qt == 256 && pl.cap < 1024) pl.cap = 1024;
     int regsel_max = KNN_REGISTER_SELECT_MAX_K;
 #ifdef KNN355_DEV
     if (getenv("KNN355_REGSEL_MAX_K")) regsel_max = atoi(getenv("KNN355_REGSEL_MAX_K")); // (developer build: where the 4096-key lists take over)
@@ -2985,7 +3483,7 @@ static void make_plan(const knn_index_s *h, int64_t nb, int64_t nq, int k, bool 
     else if (k <= KNN_WAVE_SELECT_MAX_K) pl.cap = std::min(pl.cap, 4096);  // wave_select_mem: 1.25 k + a tile of appends fit
     const int64_t ntiles = (nb + pl.dt - 1) / pl.dt;
     pl.npairs = 0;
-    if (allow_pairs && pl.nqtiles == 1 && h->force_chunks <= 0 && !(h->flags & 4) && ntiles >= (int64_t)dev_knob("KNN355_PAIR_MIN_TILES", 64)) {
+    if (allow_pairs && pl.nqtiles == 1 && qt != 256 && h->force_chunks <= 0 && !(h->flags & 4) && ntiles >= (int64_t)dev_knob("KNN355_PAIR_MIN_TILES", 64)) {
         // one query tile, plenty of tiles: two workgroups per CU, paired (see flat_scan_kernel): each pair shares a
         // contiguous range of ~ ntiles / CUs tiles (at least two: fewer pairs than CUs on a small database)
         pl.npairs = (int)std::min<int64_t>(std::max(1, h->num_cus), ntiles / 2);
@@ -2997,7 +3495,9 @@ static void make_plan(const knn_index_s *h, int64_t nb, int64_t nq, int k, bool 
         pl.lds = std::max((size_t)2 * (pl.dt + pl.qt) * 128, (size_t)pl.cap * 8) + (size_t)qt * 12 + 16 + (size_t)pl.dt * 4 + (size_t)qt * 8;
         return;
     }
-    int64_t want = h->force_chunks > 0 ? h->force_chunks : (1024 + pl.nqtiles - 1) / pl.nqtiles;
+    // workgroups resident per CU: two, or the one 256 x 256 workgroup
+    const int per_cu = qt == 256 ? 1 : 2;
+    int64_t want = h->force_chunks > 0 ? h->force_chunks : (512 * per_cu + pl.nqtiles - 1) / pl.nqtiles;
     // an unseeded chunk should see enough rows to amortise its threshold warm-up; a seeded pass
     // starts with good thresholds and a tiny view (a seed sample) just wants parallelism
     int64_t min_tiles = std::max<int64_t>(2, (4 * (int64_t)k + pl.dt - 1) / pl.dt);
@@ -3012,7 +3512,7 @@ static void make_plan(const knn_index_s *h, int64_t nb, int64_t nq, int k, bool 
         // wave quantisation: workgroups run in rounds of (2 per CU); pick the chunk count near
         // `want` that minimises rounds x tiles-per-chunk (14433 x 14433: 9 chunks = 2 full
         // rounds of 13 tiles beat 10 chunks = 2.2 rounds of 12)
-        const int64_t slots = 2 * (int64_t)std::max(1, h->num_cus);
+        const int64_t slots = per_cu * (int64_t)std::max(1, h->num_cus);
         int64_t best = want, best_cost = INT64_MAX;
         for (int64_t c = std::max<int64_t>(1, want / 2); c <= std::min(want_max, want + want / 2 + 1); c++) {
             const int64_t rounds = (pl.nqtiles * c + slots - 1) / slots;
@@ -3096,7 +3596,9 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     const int64_t nb = view_rows(h->ntotal, row_mul, vshift);
     ScanPlan pl;
     const bool allow_pairs = !h->approx16; // (the bf16 build has no one-query-tile streaming case worth pairing)
-    make_plan(h, nb, nq, k, true, pl, allow_pairs);
+    // (the 256 x 256 tile needs the statistical seed -- see below -- so only callers that can check its verification flag get it)
+    const bool allow_big = (allow_stat && level == 0 && row_mul == 1 && !(h->flags & (8 | 16 | 512))) || (h->flags & 524288);
+    make_plan(h, nb, nq, k, true, pl, allow_pairs, allow_big);
     if (level >= knn_index_s::MAX_LEVELS) return set_err(KNN_ERR_INVALID, "search: seed recursion too deep");
     // Exact seeding pays when the sample that gives every chunk a tight threshold (about two chunks'
     // worth of rows, at least 64 k) is a small fraction of the view: the streaming regime (few
@@ -3112,6 +3614,16 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
         // statistical seed: single rows, every 32nd (every 16th of a small database, every 64th of a
         // large one): a few percent of the work, one round of workgroups at CATH size
         int st = nb >= (1 << 20) ? 64 : (nb >= 8192 ? 32 : 16);
+        // The 256 x 256 tile (one workgroup per CU) ALWAYS wants the estimate, and from a sparser sample: nothing on the CU hides
+        // an unseeded chunk's warm-up -- every score appended until the lists first fill, a stale bound for the ~25 tiles up to
+        // the next cut (10 % of the scores pass: the sparse epilogue's lanes run out of slots and the tiles are filtered the
+        // dense way), cuts of 256 lists on four waves -- Pfam-sized k = 100: 52.2 ms per 16384-query launch unseeded, 48.1
+        // seeded; and the sample pass is what the seed costs: 1.93 ms per launch with every 32nd row, a quarter of that with
+        // every 128th, for twice the candidates (0.8 % of the scores instead of 0.4 %: the epilogue does not notice).
+        ScanPlan un;
+        make_plan(h, nb, nq, k, false, un, false, allow_big);
+        const bool big = un.qt == 256;
+        if (big) st *= k <= 256 ? 4 : 2;
 #ifdef KNN355_DEV
         if (getenv("KNN355_STAT_STRIDE")) st = atoi(getenv("KNN355_STAT_STRIDE")); // (developer build: the statistical sample's stride)
 #endif
@@ -3120,8 +3632,6 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
         const int j = stat_seed_rank(S, nb, k);
         if (j > 0 && (force || (nq >= dev_knob("KNN355_STAT_MIN_NQ", 65) && nb >= 8192))) {
             // worth it only if it removes most of the candidates an unseeded pass would collect
-            ScanPlan un;
-            make_plan(h, nb, nq, k, false, un);
             // (an unseeded chunk appends every score until its list first fills, cap - dt keys, whatever k is; then about
             // k more per e-fold of rows)
             const double warm = std::min<double>((double)un.cap - un.dt, (double)un.chunk_rows);
@@ -3130,7 +3640,7 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
             // ... and if those candidates are a sizeable share of all scores (Pfam-sized k = 100: 5 % of the scores go
             // through the lists, an unseeded scan loses ~5 % to them and the sample pass would cost 3 %: not worth it;
             // k = 1000: 17 %, CATH-sized k = 301: 50 %)
-            if (force || (seeded <= 0.5 * unseeded && unseeded >= 0.08 * (double)nb)) {
+            if (force || big || (seeded <= 0.5 * unseeded && unseeded >= 0.08 * (double)nb)) {
                 sstride = st;
                 seed_j = j;
                 seed_stat = 1;
@@ -3179,7 +3689,7 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
             expect_n = 1.3 * (-P * log(1.0 - (double)k / P)) * (double)nb / ((double)pub_rounds * pl.nchunks * pl.dt) + 2.0 * k + 64;
         }
     }
-    if (!sstride && !pub_rounds) make_plan(h, nb, nq, k, level > 0, pl, allow_pairs && level == 0); // a seed sample is small: parallelism over warm-up
+    if (!sstride && !pub_rounds) make_plan(h, nb, nq, k, level > 0, pl, allow_pairs && level == 0, allow_big); // a seed sample is small: parallelism over warm-up
     // Most keys a chunk hands on per query.  Chunks of a single tile (a seed sample, a tiny database)
     // hand on ALL their candidates: cutting 32 lists of one tile down to 1.25 k at the end of the only
     // tile is serial work per workgroup that the final selection does anyway, one workgroup per query.
@@ -3273,7 +3783,7 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
         HIP_TRY(hipGetLastError());
         p.xq_diff = (const float *)h->ws_qdiff.p;
     }
-    if (pl.nqtiles > 1 && !h->approx16 && pl.tiles_base >= 2 && !(h->flags & 256)) { // (turn taking: batch launches with real chunks)
+    if (pl.nqtiles > 1 && !h->approx16 && pl.tiles_base >= 2 && pl.qt != 256 && !(h->flags & 256)) { // (turn taking: batch launches with real chunks, two workgroups per CU)
         if (h->ws_turn.ensure(2048 * 4, h->done, s)) return set_err(KNN_ERR_HIP, "search: out of device memory");
         HIP_TRY(hipMemsetAsync(h->ws_turn.p, 0, 2048 * 4, s));
         p.cu_turn = (uint32_t *)h->ws_turn.p;
@@ -3309,7 +3819,8 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
         h->nlaunches++;
         HIP_TRY(hipEventRecord(h->ev0, s));
     }
-    if (pl.qt == 128) rc = launch_scan_cfg<2, 2, 2, 2>(h, p, pl, s);
+    if (pl.qt == 256) rc = launch_scan_big(h, p, pl, s);
+    else if (pl.qt == 128) rc = launch_scan_cfg<2, 2, 2, 2>(h, p, pl, s);
     else if (pl.qt == 96) rc = launch_scan16<2, 2, 2, 3>(h, p, pl, s);
     else if (pl.qt == 48) rc = launch_scan16<4, 1, 2, 3>(h, p, pl, s);
     else if (pl.qt == 64) rc = launch_scan_cfg<2, 2, 2, 1>(h, p, pl, s);
@@ -3619,10 +4130,14 @@ static int self_search_symmetric(knn_index_s *h, int k, float *D_dev, int64_t *I
     const int64_t S = view_rows(n, st, 0);
     const double expect = 1.3 * (double)j * (double)n / (double)S + 1.25 * k;
     ScanPlan pl;
-    make_plan(h, n, n, k, true, pl); // (tile shape, list capacity, LDS)
-    if (pl.qt != 128 || pl.dt != 128) return 0;
-    const int T = (int)((n + 127) / 128);
-    const size_t nslots = (size_t)T * 128;
+    // (tile shape, list capacity, LDS.  256-row tiles only on demand, flags & 524288: the symmetric launch filters every tile
+    // twice and executes half the flops per row pair, its epilogue weighs twice as much beside the K loop -- Pfam-sized
+    // k = 100 / 1000: 372.7 / 392.6 ms on 256-row tiles against 349.7 / 377.4 on 128-row tiles, one box)
+    make_plan(h, n, n, k, true, pl, false, (h->flags & 524288) != 0);
+    if (pl.qt != pl.dt || (pl.qt != 128 && pl.qt != 256)) return 0;
+    const int TS = pl.qt; // square tiles of 128 rows (two workgroups per CU) or 256 rows (one: flat_scan_kernel<2, 2, 4, 4>, large indexes)
+    const int T = (int)((n + TS - 1) / TS);
+    const size_t nslots = (size_t)T * TS;
     LevelBufs &lb = h->ws_level[0];
     lb.clean_sig = 0; // (this search leaves the level's state in its own shape)
     if (lb.qlist.ensure((size_t)n * qcap * 8) || lb.qcnt.ensure((size_t)n * 4) || lb.gthr.ensure(nslots * 4) || lb.qthr.ensure((size_t)n * 4) ||
@@ -3635,11 +4150,11 @@ static int self_search_symmetric(knn_index_s *h, int k, float *D_dev, int64_t *I
     //    rounds x (tiles + half a tile of fixed work), two workgroups per CU.  The table depends on (tiles, CUs) only: it
     //    stays on the device between searches (uploading it between the sample pass and the main launch cost a host
     //    round trip -- 35 us of idle GPU -- per search).
-    const int64_t slots = 2 * (int64_t)std::max(1, h->num_cus);
+    const int64_t slots = (TS == 256 ? 1 : 2) * (int64_t)std::max(1, h->num_cus);
     constexpr int SYM_GROUPS = 8;
     const bool stream_out = D_host && I_host && d2h && (size_t)n * k * 12 >= ((size_t)256 << 20) && T >= 16 * SYM_GROUPS;
     const int groups = stream_out ? SYM_GROUPS : 1;
-    if (h->sym_tiles != T || h->sym_groups != groups || !h->ws_sym.p) {
+    if (h->sym_tiles != T || h->sym_ts != TS || h->sym_groups != groups || !h->ws_sym.p) {
         int best_tp = 16;
         int64_t best_cost = INT64_MAX;
         for (int tp = dev_knob("KNN355_SYM_MIN_TP", 1); tp <= 96; tp++) {
@@ -3664,6 +4179,7 @@ static int self_search_symmetric(knn_index_s *h, int k, float *D_dev, int64_t *I
         HIP_TRY(hipMemcpyAsync(h->ws_sym.p, items.data(), items.size() * sizeof(SymItem), hipMemcpyHostToDevice, s));
         HIP_TRY(hipStreamSynchronize(s)); // (the table is a local vector)
         h->sym_tiles = T;
+        h->sym_ts = TS;
         h->sym_groups = groups;
         h->sym_run = best_tp;
         h->sym_items = (int64_t)items.size();
@@ -3689,13 +4205,14 @@ static int self_search_symmetric(knn_index_s *h, int k, float *D_dev, int64_t *I
     p.id_base = 0; p.row_mul = 1; p.vshift = 0; p.skip_mask = st - 1;
     p.kslot = knn_kslot(k);
     p.fail = (int *)h->ws_flag.p;
-    if (!(h->flags & 256)) {
+    if (!(h->flags & 256) && TS == 128) {
         if (h->ws_turn.ensure(2048 * 4)) return set_err(KNN_ERR_HIP, "search_self: out of device memory");
         HIP_TRY(hipMemsetAsync(h->ws_turn.p, 0, 2048 * 4, s));
         p.cu_turn = (uint32_t *)h->ws_turn.p;
     }
     const size_t lds = pl.lds + (size_t)(2 + 2) * pl.dt * 4; // + thresholds, per-half counts and bases of the tile's rows
     void (*kern)(ScanParams) = h->metric == KNN_METRIC_L2 ? flat_scan_kernel<2, 2, 2, 2, true, false, true> : flat_scan_kernel<2, 2, 2, 2, false, false, true>;
+    if (TS == 256) kern = h->metric == KNN_METRIC_L2 ? flat_scan_kernel<2, 2, 4, 4, true, false, true> : flat_scan_kernel<2, 2, 4, 4, false, false, true>;
     HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
         const int slot = (int)(h->nlaunches % knn_index_s::RING);
@@ -3730,7 +4247,7 @@ static int self_search_symmetric(knn_index_s *h, int k, float *D_dev, int64_t *I
             HIP_TRY(hipGetLastError());
         }
         if (g == groups - 1) HIP_TRY(hipEventRecord(h->ev1, s));
-        const int64_t r0 = std::min<int64_t>(n, (int64_t)T * g / groups * 128), r1 = std::min<int64_t>(n, (int64_t)T * (g + 1) / groups * 128);
+        const int64_t r0 = std::min<int64_t>(n, (int64_t)T * g / groups * TS), r1 = std::min<int64_t>(n, (int64_t)T * (g + 1) / groups * TS);
         SelectParams sp = {};
         sp.in = qlist + (size_t)r0 * qcap; sp.in_stride = qcap; sp.cnt = qcnt + r0; sp.cap = qcap;
         sp.n_expect = (int)std::min<double>((double)qcap, expect);
@@ -3744,7 +4261,7 @@ static int self_search_symmetric(knn_index_s *h, int k, float *D_dev, int64_t *I
             HIP_TRY(hipEventRecord(gev[g], s));
         }
     }
-    h->last_kernel = "flat_scan_q128_d128_sym"; h->last_qt = 128; h->last_dt = 128; h->last_chunks = best_tp; h->last_grid = (int)nitems;
+    h->last_kernel = TS == 256 ? "flat_scan_q256_d256_sym" : "flat_scan_q128_d128_sym"; h->last_qt = TS; h->last_dt = TS; h->last_chunks = best_tp; h->last_grid = (int)nitems;
     h->last_seed_stride = st; h->last_seed_stat = j; h->last_sample_rows = S;
     if (h->done) (void)hipEventRecord(h->done, s); // (everything this search enqueued on the handle's buffers: see DevBuf::ensure)
     h->sym_searches++;
@@ -3753,7 +4270,7 @@ static int self_search_symmetric(knn_index_s *h, int k, float *D_dev, int64_t *I
     // block this thread as long as it likes)
     hipError_t e = hipSuccess;
     for (int g = 0; g < groups; g++) {
-        const int64_t r0 = std::min<int64_t>(n, (int64_t)T * g / groups * 128), r1 = std::min<int64_t>(n, (int64_t)T * (g + 1) / groups * 128);
+        const int64_t r0 = std::min<int64_t>(n, (int64_t)T * g / groups * TS), r1 = std::min<int64_t>(n, (int64_t)T * (g + 1) / groups * TS);
         if (e == hipSuccess) e = hipStreamWaitEvent(d2h, gev[g], 0);
         if (e == hipSuccess && r1 > r0) e = hipMemcpyAsync(D_host + (size_t)r0 * k, D_dev + (size_t)r0 * k, (size_t)(r1 - r0) * k * 4, hipMemcpyDeviceToHost, d2h);
         if (e == hipSuccess && r1 > r0) e = hipMemcpyAsync(I_host + (size_t)r0 * k, I_dev + (size_t)r0 * k, (size_t)(r1 - r0) * k * 8, hipMemcpyDeviceToHost, d2h);
@@ -4173,8 +4690,8 @@ extern "C" int knn_flat_reserve(knn_handle h, int64_t nrows)
 extern "C" int knn_set_tuning(knn_handle h, int32_t query_tile, int32_t nchunks, int32_t flags)
 {
     if (!h) return set_err(KNN_ERR_INVALID, "null handle");
-    if (query_tile != 0 && query_tile != 32 && query_tile != 48 && query_tile != 64 && query_tile != 96 && query_tile != 128)
-        return set_err(KNN_ERR_INVALID, "set_tuning: query_tile must be 0, 32, 48, 64, 96 or 128");
+    if (query_tile != 0 && query_tile != 32 && query_tile != 48 && query_tile != 64 && query_tile != 96 && query_tile != 128 && query_tile != 256)
+        return set_err(KNN_ERR_INVALID, "set_tuning: query_tile must be 0, 32, 48, 64, 96, 128 or 256");
     std::lock_guard<std::mutex> lk(h->mu);
     h->force_qt = query_tile;
     h->force_chunks = nchunks;

@@ -30,5 +30,6 @@ for rep in range(2):
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 _lib.check(call())
                 torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
-            out.append(f"{name} {1e3*min(ts[1:]):8.1f} ms ({2.0*n*n*d/min(ts[1:])/1e12:6.1f} TFLOP/s of the full matrix)")
+            info = idx.last_scan()
+            out.append(f"{name} {1e3*min(ts[1:]):8.1f} ms ({2.0*n*n*d/min(ts[1:])/1e12:6.1f} TFLOP/s of the full matrix; last launch {info['kernel']} {info['ms']:.2f} ms grid {info['grid']} seed {idx.last_seed()['stat_rank']})")
         print(f"k {k} flags {flags:4d}: " + "   ".join(out), flush=True)
