@@ -57,6 +57,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef KNN355_DIFF_SCALAR_PAIRS
 #define KNN355_DIFF_SCALAR_PAIRS 3 // ... the first three query pairs of a thread's half (all of them up to 12 queries), the others through the LDS
 #endif
+#ifndef KNN355_EPI_PRIO
+#define KNN355_EPI_PRIO 2 // issue priority of a wave behind its K loop (two workgroups per CU; 0: never raised, for the A/B)
+#endif
 #ifndef KNN355_STREAM_DMA_FIRST
 #define KNN355_STREAM_DMA_FIRST 1 // streaming launches issue a K step's staging instructions in front of its first MFMA (flat_scan_kernel)
 #endif
@@ -709,9 +712,11 @@ struct ScanParams {
 #ifdef KNN355_TRACE
 #define KNN_TRACE(slot) do { if (threadIdx.x == 0 && p.trace && (slot) < 128) p.trace[(size_t)blockIdx.x * 128 + (slot)] = wall_clock64(); } while (0)
 #define KNN_TRACE_AT(cond, slot) do { if (cond) KNN_TRACE(slot); } while (0)
+#define KNN_TRACE_COUNT(cond, slot) do { if (threadIdx.x == 0 && p.trace && (cond)) p.trace[(size_t)blockIdx.x * 128 + (slot)] += 1; } while (0)
 #else
 #define KNN_TRACE(slot) do { } while (0)
 #define KNN_TRACE_AT(cond, slot) do { } while (0)
+#define KNN_TRACE_COUNT(cond, slot) do { } while (0)
 #endif
 
 // Views: view row r of a launch with stride row_mul and block size B = 1 << vshift is database row
@@ -994,6 +999,10 @@ __global__ __launch_bounds__(256, (TM * TN >= 16 ? 1 : 2)) void flat_scan_kernel
     constexpr int QT = WN * (M16 ? Q16 * 16 : TN * 32); // queries per workgroup
     constexpr int NB = M16 ? Q16 : TN;      // query blocks of a wave (of 16 / 32 queries)
     constexpr int NS = TM * (M16 ? 8 : 16); // scores of one query block a lane holds per tile
+    constexpr bool BIGT = TM * TN >= 16;    // the 256 x 256 tile: one workgroup per CU, accumulators in AGPRs, late-barrier K loop
+    // the batch builds (several query tiles per launch, plain fp32): the 128 x 128 and the 256 x 256 tile filter their scores
+    // through the sparse epilogue
+    constexpr bool SPARSE = !NTDB && !BF16 && DNQ == 0 && Q16 == 0 && WM == 2 && WN == 2 && TM == TN && (TM == 2 || TM == 4);
     constexpr int ROWS = DT + QT;           // staged rows per K step
     constexpr int NGRP = ROWS / 8;          // staging instructions per K step (8 rows each) ...
     constexpr int NI = (NGRP + 3) / 4;      // ... per wave; a wave short of one (304 rows: 38 over 4 waves) repeats its previous one
@@ -1002,7 +1011,8 @@ __global__ __launch_bounds__(256, (TM * TN >= 16 ? 1 : 2)) void flat_scan_kernel
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *stage0 = smem;
     char *stage1 = smem + STAGE_BYTES;
-    const int lds_main = max(2 * STAGE_BYTES, p.cap * 8);
+    // (the symmetric 128 x 128 build's sparse epilogue keeps 36 slots of 2 KB: 8 KB more than the two staging buffers)
+    const int lds_main = max(max(2 * STAGE_BYTES, p.cap * 8), SYM && TM * TN == 4 ? 73728 : 0);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1121,7 +1131,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 16 ? 1 : 2)) void flat_scan_kernel
     // queries may be candidates of the symmetric launch's second direction (real rows the sample pass has not handed on)
     float big_xnq[NB];
     uint64_t big_cokm[NB];
-    if constexpr (TM * TN >= 16) {
+    if constexpr (SPARSE) {
 #pragma unroll
         for (int b = 0; b < NB; b++) {
             const int64_t q = q0 + (M16 ? 0 : (wn * TN + b) * 32 + li);
@@ -1215,7 +1225,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 16 ? 1 : 2)) void flat_scan_kernel
         // them one after the other were 8 of the epilogue's 10 us; read in front of the K loop they cost nothing, and a bound
         // one tile old only admits a few candidates more (thresholds only ever tighten)
         float big_thr[NB];
-        if constexpr (TM * TN >= 16) {
+        if constexpr (SPARSE) {
 #pragma unroll
             for (int b = 0; b < NB; b++) {
                 const int ql = M16 ? 0 : (wn * TN + b) * 32 + li;
@@ -1225,7 +1235,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 16 ? 1 : 2)) void flat_scan_kernel
         if constexpr (SYM) {
             if (tid < DT) // rows past the end are nobody's query: nothing beats -inf
                 s_thr2[tid] = row0 + tid < p.nb ? ord2f(__hip_atomic_load(&p.gthr[row0 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : -INFINITY;
-            if constexpr (TM * TN >= 16) { // (the sparse epilogue's per-row counters and its "this tile is dense" flag; visible behind the K loop's barriers)
+            if constexpr (SPARSE) { // (the sparse epilogue's per-row counters and its "this tile is dense" flag; visible behind the K loop's barriers)
                 if (tid < DT) s_cnt2[tid] = 0;
                 if (tid == 0) L.s_need[2] = 0;
             }
@@ -1455,7 +1465,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 16 ? 1 : 2)) void flat_scan_kernel
         auto no_dma = [](int) {};
         using nd_none = std::integral_constant<int, 0>;
         using nd_all = std::integral_constant<int, NI>;
-        if constexpr (TM * TN >= 16) {
+        if constexpr (BIGT) {
             // ---- the 256 x 256 tile's K loop: ONE wave per SIMD, so nothing but this wave's own instruction order hides a
             // latency.  One barrier per K step, in front of the step's LAST sub-step ("late barrier"):
             //   sub-step 0, 1   MFMAs; the staging instructions of K step kt + 1 (groups A, B) between them
@@ -1651,6 +1661,13 @@ __global__ __launch_bounds__(256, (TM * TN >= 16 ? 1 : 2)) void flat_scan_kernel
             __syncthreads();           // (the next tile's prologue stages into these buffers)
         }
         KNN_TRACE(1 + 2 * tile_idx);
+        // Two workgroups per CU: behind its K loop a wave's vector instructions compete with the MFMAs of the OTHER workgroup's
+        // wave on the same SIMD, and that wave -- usually the older one -- wins the arbitration: the epilogue got about one
+        // instruction in per MFMA of the neighbour (the sparse epilogue of a CATH-sized symmetric tile, ~1500 instructions:
+        // 40-70 us beside a 75 us K loop, per-workgroup stamps; alone on the SIMD the same code takes 3 us).  Priority outranks
+        // age: raised for the epilogue, lowered again in front of the next K loop.  A dozen vector instructions fit into every
+        // gap of the neighbour's 64-cycle MFMAs, so its K loop does not pay for them.
+        if constexpr (!BIGT && KNN355_EPI_PRIO > 0) __builtin_amdgcn_s_setprio(KNN355_EPI_PRIO);
         if (paired && tid == 0) *s_next = next_tile; // (read by everyone behind the barrier that ends the epilogue)
 
         // score s of query block b in this lane (see accv / rowl) -- "smaller is better"
@@ -1833,40 +1850,47 @@ __global__ __launch_bounds__(256, (TM * TN >= 16 ? 1 : 2)) void flat_scan_kernel
         auto sparse_epilogue = [&](int64_t trow0, bool second, auto *dense2) { // (generic: only the 256 x 256 builds instantiate it)
             // slots per lane and tile, first / second direction (+ a dump slot each), all inside staging buffer 1: buffer 0 is
             // taking the next tile's first K step meanwhile
-            constexpr int C1 = SYM ? 24 : 31, C2 = SYM ? 6 : 0;
-            constexpr int OFF1 = STAGE_BYTES, OFF2 = OFF1 + (C1 + 1) * 2048; // the second direction's slots start behind the first's
-            static_assert(OFF2 + (SYM ? (C2 + 1) * 2048 : 0) <= 2 * STAGE_BYTES, "the lanes' slots fit staging buffer 1");
-            static_assert(NS == 64 && NB == 4, "score numbers are sc | block << 8");
+            // Slots per lane and tile (+ a dump slot).  256 x 256 tile: inside staging buffer 1 (buffer 0 is taking the next tile's
+            // first K step meanwhile); 128 x 128 tile: both of its 32-KB staging buffers are idle during the epilogue, the
+            // symmetric build adds 8 KB (lds_main).  The symmetric launch's two directions use the SAME slots, one after the
+            // other: their survivor counts per lane have different tails (squared L2 on raw embeddings has hubs -- a candidate
+            // of small norm beats the bound of every row: CATH-sized k = 301, a lane's largest count in a launch: first direction
+            // 15, second 27 of its 64 scores, the mean 4.7), and half the slots each sent the second direction of nearly every
+            // tile the dense way.
+            constexpr int C = BIGT ? 31 : (SYM ? 35 : 30);
+            constexpr int OFF1 = BIGT ? STAGE_BYTES : 0;
+            static_assert(OFF1 + (C + 1) * 2048 <= (SYM && !BIGT ? 73728 : 2 * STAGE_BYTES), "the lanes' slots fit the staging buffer(s)");
+            static_assert(NS % 16 == 0 && NS <= 64 && NB <= 4, "score numbers are sc | block << 8");
             const bool ragged = trow0 + DT > p.nb, sampled = p.skip_mask >= 0, plain_rows = p.row_mul == 1;
             const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)smem);
             int *s_dense = L.s_need + 2;
             const float *thr = big_thr, *xnq = big_xnq;
             const uint64_t *cokm = big_cokm;
             KNN_TRACE_AT(tile_idx == 5, 124);
-            const uint32_t w1_0 = lds0 + OFF1 + tid * 8, w2_0 = lds0 + OFF2 + tid * 8;
-            uint32_t w1 = w1_0, w2 = w2_0;                          // LDS address of this lane's next slot (counts on past the last)
-            const uint32_t dump1 = w1_0 + C1 * 2048, dump2 = w2_0 + C2 * 2048;
-            const uint32_t step = 2048;
+            const uint32_t w_0 = lds0 + OFF1 + tid * 8;              // LDS address of this lane's first slot
+            const uint32_t dump = w_0 + C * 2048, step = 2048;
             const float ninf = -INFINITY;
+            uint32_t w = w_0;                                        // ... of its next slot (counts on past the last)
+            uint32_t nblk[NB] = {};                                  // first direction: 2048 x this lane's survivors of each query block
             KNN_TRACE_AT(tile_idx == 5, 125);
-            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");       // (the K loop's last MFMAs -> v_accvgpr_read inside the statements below)
-            // (one body per case, chosen once: with `second` tested inside, the compiler put a branch and a handful of spills
-            // around every statement of the symmetric builds)
-            uint32_t nblk[NB] = {}; // first direction: 2048 x this lane's survivors of each query block
-            auto pass1 = [&](auto second_tag) {
-                (void)&w2; (void)&ninf; (void)&dump2; (void)&cokm; // (named here: captures that only a discarded branch uses are not made)
-                // four scores per statement: their value / compare chains are independent and issue back to back (one wave per SIMD:
-                // a chain on its own waits out every instruction's latency), only the pointer bumps are serial
+            if constexpr (BIGT) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); // (the K loop's last MFMAs -> v_accvgpr_read inside the statements below)
+            // Pass 1 of one direction.  Four scores per statement: their value / compare chains are independent and issue back to
+            // back (a chain on its own waits out every instruction's latency), only the pointer bumps are serial.  No exec mask, no
+            // scalar instruction: EVERY lane stores (value, score number) into its next slot -- a score that fails is overwritten
+            // by the lane's next survivor, which lands in the same slot -- and only a survivor moves the pointer on.
+            auto pass1 = [&](auto dir_tag) {
+                constexpr int DIR = decltype(dir_tag)::value;
+                (void)&ninf; (void)&cokm; (void)&thr; (void)&nblk; // (named here: captures that only a discarded branch uses are not made)
 #pragma unroll
                 for (int c = 0; c < NS; c += 16) {
                     // the norms / second-direction thresholds of this chunk's 16 rows: four consecutive rows per 16-byte LDS read
-                    // (all 64 rows of the tile at once cost 128 registers in the symmetric L2 build: spills between the statements)
+                    // (all 64 rows of the 256-row tile at once cost 128 registers in the symmetric L2 build: spills between the statements)
                     float ynl[16], t2l[16];
 #pragma unroll
                     for (int i = 0; i < 16; i += 4) {
                         f32x4 y4 = {0.0f, 0.0f, 0.0f, 0.0f}, h4 = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
                         if constexpr (L2) y4 = *(const f32x4 *)&s_yn[rowl(c + i)];
-                        if constexpr (SYM) h4 = *(const f32x4 *)&s_thr2[rowl(c + i)];
+                        if constexpr (DIR == 2) h4 = *(const f32x4 *)&s_thr2[rowl(c + i)];
 #pragma unroll
                         for (int e = 0; e < 4; e++) {
                             ynl[i + e] = y4[e];
@@ -1875,93 +1899,165 @@ __global__ __launch_bounds__(256, (TM * TN >= 16 ? 1 : 2)) void flat_scan_kernel
                     }
 #pragma unroll
                     for (int b = 0; b < NB; b++) {
-                    const uint32_t w1_b = w1; // (this lane's survivors of query block b: what the 16 scores below add to the pointer)
+                        const uint32_t w_b = w; // (this lane's survivors of query block b: what the 16 scores below add to the pointer)
 #pragma unroll
-                    for (int sc = c; sc < c + 16; sc += 4) {
-                        uint32_t t[4], ad[4], ix[4], u;
-                        uint64_t mk[4];
-                        const float a0 = accv(b, sc), a1 = accv(b, sc + 1), a2 = accv(b, sc + 2), a3 = accv(b, sc + 3);
-                        if constexpr (L2) {
+                        for (int sc = c; sc < c + 16; sc += 4) {
+                            uint32_t t[4], ad[4], ix[4], e[4], u;
+                            uint64_t mk[4];
+                            (void)e; (void)t2l;
+                            const float a0 = accv(b, sc), a1 = accv(b, sc + 1), a2 = accv(b, sc + 2), a3 = accv(b, sc + 3);
                             const float s0 = xnq[b] + ynl[sc - c], s1 = xnq[b] + ynl[sc - c + 1], s2 = xnq[b] + ynl[sc - c + 2], s3 = xnq[b] + ynl[sc - c + 3];
-                            asm volatile("v_accvgpr_read_b32 %[t0], %[a0]\n\t"
-                                         "v_accvgpr_read_b32 %[t1], %[a1]\n\t"
-                                         "v_accvgpr_read_b32 %[t2], %[a2]\n\t"
-                                         "v_accvgpr_read_b32 %[t3], %[a3]\n\t"
-                                         "v_fma_f32 %[t0], %[t0], -2.0, %[s0]\n\t"
-                                         "v_fma_f32 %[t1], %[t1], -2.0, %[s1]\n\t"
-                                         "v_fma_f32 %[t2], %[t2], -2.0, %[s2]\n\t"
-                                         "v_fma_f32 %[t3], %[t3], -2.0, %[s3]\n\t"
-                                         "v_cmp_le_f32_e64 %[m0], %[t0], %[thr]\n\t"
-                                         "v_cmp_le_f32_e64 %[m1], %[t1], %[thr]\n\t"
-                                         "v_cmp_le_f32_e64 %[m2], %[t2], %[thr]\n\t"
-                                         "v_cmp_le_f32_e64 %[m3], %[t3], %[thr]\n\t"
-                                         "v_min_u32_e32 %[ad0], %[w], %[dump]\n\t"
-                                         "v_cndmask_b32_e64 %[u], 0, %[step], %[m0]\n\t"
-                                         "v_add_u32_e32 %[w], %[w], %[u]\n\t"
-                                         "v_min_u32_e32 %[ad1], %[w], %[dump]\n\t"
-                                         "v_cndmask_b32_e64 %[u], 0, %[step], %[m1]\n\t"
-                                         "v_add_u32_e32 %[w], %[w], %[u]\n\t"
-                                         "v_min_u32_e32 %[ad2], %[w], %[dump]\n\t"
-                                         "v_cndmask_b32_e64 %[u], 0, %[step], %[m2]\n\t"
-                                         "v_add_u32_e32 %[w], %[w], %[u]\n\t"
-                                         "v_min_u32_e32 %[ad3], %[w], %[dump]\n\t"
-                                         "v_cndmask_b32_e64 %[u], 0, %[step], %[m3]\n\t"
-                                         "v_add_u32_e32 %[w], %[w], %[u]\n\t"
-                                         "v_mov_b32_e32 %[i0], %[idx0]\n\t"
-                                         "v_mov_b32_e32 %[i1], %[idx1]\n\t"
-                                         "v_mov_b32_e32 %[i2], %[idx2]\n\t"
-                                         "v_mov_b32_e32 %[i3], %[idx3]\n\t"
-                                         "ds_write2_b32 %[ad0], %[t0], %[i0] offset1:1\n\t"
-                                         "ds_write2_b32 %[ad1], %[t1], %[i1] offset1:1\n\t"
-                                         "ds_write2_b32 %[ad2], %[t2], %[i2] offset1:1\n\t"
-                                         "ds_write2_b32 %[ad3], %[t3], %[i3] offset1:1"
-                                         : [t0] "=&v"(t[0]), [t1] "=&v"(t[1]), [t2] "=&v"(t[2]), [t3] "=&v"(t[3]), [ad0] "=&v"(ad[0]), [ad1] "=&v"(ad[1]), [ad2] "=&v"(ad[2]), [ad3] "=&v"(ad[3]), [i0] "=&v"(ix[0]), [i1] "=&v"(ix[1]), [i2] "=&v"(ix[2]), [i3] "=&v"(ix[3]), [m0] "=&s"(mk[0]), [m1] "=&s"(mk[1]), [m2] "=&s"(mk[2]), [m3] "=&s"(mk[3]), [u] "=&v"(u), [w] "+v"(w1)
-                                         : [a0] "a"(a0), [a1] "a"(a1), [a2] "a"(a2), [a3] "a"(a3), [s0] "v"(s0), [s1] "v"(s1), [s2] "v"(s2), [s3] "v"(s3),
-                                           [thr] "v"(thr[b]), [dump] "v"(dump1), [step] "v"(step), [idx0] "n"((sc + 0) | (b << 8)), [idx1] "n"((sc + 1) | (b << 8)), [idx2] "n"((sc + 2) | (b << 8)), [idx3] "n"((sc + 3) | (b << 8))
-                                         : "memory");
-                        } else {
-                            asm volatile("v_accvgpr_read_b32 %[t0], %[a0]\n\t"
-                                         "v_accvgpr_read_b32 %[t1], %[a1]\n\t"
-                                         "v_accvgpr_read_b32 %[t2], %[a2]\n\t"
-                                         "v_accvgpr_read_b32 %[t3], %[a3]\n\t"
-                                         "v_xor_b32_e32 %[t0], 0x80000000, %[t0]\n\t"
-                                         "v_xor_b32_e32 %[t1], 0x80000000, %[t1]\n\t"
-                                         "v_xor_b32_e32 %[t2], 0x80000000, %[t2]\n\t"
-                                         "v_xor_b32_e32 %[t3], 0x80000000, %[t3]\n\t"
-                                         "v_cmp_le_f32_e64 %[m0], %[t0], %[thr]\n\t"
-                                         "v_cmp_le_f32_e64 %[m1], %[t1], %[thr]\n\t"
-                                         "v_cmp_le_f32_e64 %[m2], %[t2], %[thr]\n\t"
-                                         "v_cmp_le_f32_e64 %[m3], %[t3], %[thr]\n\t"
-                                         "v_min_u32_e32 %[ad0], %[w], %[dump]\n\t"
-                                         "v_cndmask_b32_e64 %[u], 0, %[step], %[m0]\n\t"
-                                         "v_add_u32_e32 %[w], %[w], %[u]\n\t"
-                                         "v_min_u32_e32 %[ad1], %[w], %[dump]\n\t"
-                                         "v_cndmask_b32_e64 %[u], 0, %[step], %[m1]\n\t"
-                                         "v_add_u32_e32 %[w], %[w], %[u]\n\t"
-                                         "v_min_u32_e32 %[ad2], %[w], %[dump]\n\t"
-                                         "v_cndmask_b32_e64 %[u], 0, %[step], %[m2]\n\t"
-                                         "v_add_u32_e32 %[w], %[w], %[u]\n\t"
-                                         "v_min_u32_e32 %[ad3], %[w], %[dump]\n\t"
-                                         "v_cndmask_b32_e64 %[u], 0, %[step], %[m3]\n\t"
-                                         "v_add_u32_e32 %[w], %[w], %[u]\n\t"
-                                         "v_mov_b32_e32 %[i0], %[idx0]\n\t"
-                                         "v_mov_b32_e32 %[i1], %[idx1]\n\t"
-                                         "v_mov_b32_e32 %[i2], %[idx2]\n\t"
-                                         "v_mov_b32_e32 %[i3], %[idx3]\n\t"
-                                         "ds_write2_b32 %[ad0], %[t0], %[i0] offset1:1\n\t"
-                                         "ds_write2_b32 %[ad1], %[t1], %[i1] offset1:1\n\t"
-                                         "ds_write2_b32 %[ad2], %[t2], %[i2] offset1:1\n\t"
-                                         "ds_write2_b32 %[ad3], %[t3], %[i3] offset1:1"
-                                         : [t0] "=&v"(t[0]), [t1] "=&v"(t[1]), [t2] "=&v"(t[2]), [t3] "=&v"(t[3]), [ad0] "=&v"(ad[0]), [ad1] "=&v"(ad[1]), [ad2] "=&v"(ad[2]), [ad3] "=&v"(ad[3]), [i0] "=&v"(ix[0]), [i1] "=&v"(ix[1]), [i2] "=&v"(ix[2]), [i3] "=&v"(ix[3]), [m0] "=&s"(mk[0]), [m1] "=&s"(mk[1]), [m2] "=&s"(mk[2]), [m3] "=&s"(mk[3]), [u] "=&v"(u), [w] "+v"(w1)
-                                         : [a0] "a"(a0), [a1] "a"(a1), [a2] "a"(a2), [a3] "a"(a3),
-                                           [thr] "v"(thr[b]), [dump] "v"(dump1), [step] "v"(step), [idx0] "n"((sc + 0) | (b << 8)), [idx1] "n"((sc + 1) | (b << 8)), [idx2] "n"((sc + 2) | (b << 8)), [idx3] "n"((sc + 3) | (b << 8))
-                                         : "memory");
-                        }
-                        if constexpr (SYM) {
-                            if constexpr (decltype(second_tag)::value) { // (workgroup-uniform) the same values decide for rows rowl(sc ..) as queries; a lane whose own query
-                                          // is no candidate -- past the end, or a row of the sample -- compares against -inf
-                                uint32_t e[4];
-                                asm volatile("v_cndmask_b32_e64 %[e0], %[ninf], %[h0], %[cok]\n\t"
+                            (void)s0; (void)s1; (void)s2; (void)s3;
+                            if constexpr (DIR == 1) {
+                                if constexpr (BIGT && L2) {
+                                    asm volatile("v_accvgpr_read_b32 %[t0], %[a0]\n\t"
+                                             "v_accvgpr_read_b32 %[t1], %[a1]\n\t"
+                                             "v_accvgpr_read_b32 %[t2], %[a2]\n\t"
+                                             "v_accvgpr_read_b32 %[t3], %[a3]\n\t"
+                                             "v_fma_f32 %[t0], %[t0], -2.0, %[s0]\n\t"
+                                             "v_fma_f32 %[t1], %[t1], -2.0, %[s1]\n\t"
+                                             "v_fma_f32 %[t2], %[t2], -2.0, %[s2]\n\t"
+                                             "v_fma_f32 %[t3], %[t3], -2.0, %[s3]\n\t"
+                                             "v_cmp_le_f32_e64 %[m0], %[t0], %[thr]\n\t"
+                                             "v_cmp_le_f32_e64 %[m1], %[t1], %[thr]\n\t"
+                                             "v_cmp_le_f32_e64 %[m2], %[t2], %[thr]\n\t"
+                                             "v_cmp_le_f32_e64 %[m3], %[t3], %[thr]\n\t"
+                                             "v_min_u32_e32 %[ad0], %[w], %[dump]\n\t"
+                                             "v_cndmask_b32_e64 %[u], 0, %[step], %[m0]\n\t"
+                                             "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                             "v_min_u32_e32 %[ad1], %[w], %[dump]\n\t"
+                                             "v_cndmask_b32_e64 %[u], 0, %[step], %[m1]\n\t"
+                                             "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                             "v_min_u32_e32 %[ad2], %[w], %[dump]\n\t"
+                                             "v_cndmask_b32_e64 %[u], 0, %[step], %[m2]\n\t"
+                                             "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                             "v_min_u32_e32 %[ad3], %[w], %[dump]\n\t"
+                                             "v_cndmask_b32_e64 %[u], 0, %[step], %[m3]\n\t"
+                                             "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                             "v_mov_b32_e32 %[i0], %[idx0]\n\t"
+                                             "v_mov_b32_e32 %[i1], %[idx1]\n\t"
+                                             "v_mov_b32_e32 %[i2], %[idx2]\n\t"
+                                             "v_mov_b32_e32 %[i3], %[idx3]\n\t"
+                                             "ds_write2_b32 %[ad0], %[t0], %[i0] offset1:1\n\t"
+                                             "ds_write2_b32 %[ad1], %[t1], %[i1] offset1:1\n\t"
+                                             "ds_write2_b32 %[ad2], %[t2], %[i2] offset1:1\n\t"
+                                             "ds_write2_b32 %[ad3], %[t3], %[i3] offset1:1"
+                                             : [t0] "=&v"(t[0]), [t1] "=&v"(t[1]), [t2] "=&v"(t[2]), [t3] "=&v"(t[3]), [ad0] "=&v"(ad[0]), [ad1] "=&v"(ad[1]), [ad2] "=&v"(ad[2]), [ad3] "=&v"(ad[3]), [i0] "=&v"(ix[0]), [i1] "=&v"(ix[1]), [i2] "=&v"(ix[2]), [i3] "=&v"(ix[3]), [m0] "=&s"(mk[0]), [m1] "=&s"(mk[1]), [m2] "=&s"(mk[2]), [m3] "=&s"(mk[3]), [u] "=&v"(u), [w] "+v"(w)
+                                             : [a0] "a"(a0), [a1] "a"(a1), [a2] "a"(a2), [a3] "a"(a3), [s0] "v"(s0), [s1] "v"(s1), [s2] "v"(s2), [s3] "v"(s3), [thr] "v"(thr[b]), [dump] "v"(dump), [step] "v"(step), [idx0] "n"((sc + 0) | (b << 8)), [idx1] "n"((sc + 1) | (b << 8)), [idx2] "n"((sc + 2) | (b << 8)), [idx3] "n"((sc + 3) | (b << 8))
+                                             : "memory");
+                                } else if constexpr (BIGT) {
+                                    asm volatile("v_accvgpr_read_b32 %[t0], %[a0]\n\t"
+                                             "v_accvgpr_read_b32 %[t1], %[a1]\n\t"
+                                             "v_accvgpr_read_b32 %[t2], %[a2]\n\t"
+                                             "v_accvgpr_read_b32 %[t3], %[a3]\n\t"
+                                             "v_xor_b32_e32 %[t0], 0x80000000, %[t0]\n\t"
+                                             "v_xor_b32_e32 %[t1], 0x80000000, %[t1]\n\t"
+                                             "v_xor_b32_e32 %[t2], 0x80000000, %[t2]\n\t"
+                                             "v_xor_b32_e32 %[t3], 0x80000000, %[t3]\n\t"
+                                             "v_cmp_le_f32_e64 %[m0], %[t0], %[thr]\n\t"
+                                             "v_cmp_le_f32_e64 %[m1], %[t1], %[thr]\n\t"
+                                             "v_cmp_le_f32_e64 %[m2], %[t2], %[thr]\n\t"
+                                             "v_cmp_le_f32_e64 %[m3], %[t3], %[thr]\n\t"
+                                             "v_min_u32_e32 %[ad0], %[w], %[dump]\n\t"
+                                             "v_cndmask_b32_e64 %[u], 0, %[step], %[m0]\n\t"
+                                             "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                             "v_min_u32_e32 %[ad1], %[w], %[dump]\n\t"
+                                             "v_cndmask_b32_e64 %[u], 0, %[step], %[m1]\n\t"
+                                             "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                             "v_min_u32_e32 %[ad2], %[w], %[dump]\n\t"
+                                             "v_cndmask_b32_e64 %[u], 0, %[step], %[m2]\n\t"
+                                             "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                             "v_min_u32_e32 %[ad3], %[w], %[dump]\n\t"
+                                             "v_cndmask_b32_e64 %[u], 0, %[step], %[m3]\n\t"
+                                             "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                             "v_mov_b32_e32 %[i0], %[idx0]\n\t"
+                                             "v_mov_b32_e32 %[i1], %[idx1]\n\t"
+                                             "v_mov_b32_e32 %[i2], %[idx2]\n\t"
+                                             "v_mov_b32_e32 %[i3], %[idx3]\n\t"
+                                             "ds_write2_b32 %[ad0], %[t0], %[i0] offset1:1\n\t"
+                                             "ds_write2_b32 %[ad1], %[t1], %[i1] offset1:1\n\t"
+                                             "ds_write2_b32 %[ad2], %[t2], %[i2] offset1:1\n\t"
+                                             "ds_write2_b32 %[ad3], %[t3], %[i3] offset1:1"
+                                             : [t0] "=&v"(t[0]), [t1] "=&v"(t[1]), [t2] "=&v"(t[2]), [t3] "=&v"(t[3]), [ad0] "=&v"(ad[0]), [ad1] "=&v"(ad[1]), [ad2] "=&v"(ad[2]), [ad3] "=&v"(ad[3]), [i0] "=&v"(ix[0]), [i1] "=&v"(ix[1]), [i2] "=&v"(ix[2]), [i3] "=&v"(ix[3]), [m0] "=&s"(mk[0]), [m1] "=&s"(mk[1]), [m2] "=&s"(mk[2]), [m3] "=&s"(mk[3]), [u] "=&v"(u), [w] "+v"(w)
+                                             : [a0] "a"(a0), [a1] "a"(a1), [a2] "a"(a2), [a3] "a"(a3), [thr] "v"(thr[b]), [dump] "v"(dump), [step] "v"(step), [idx0] "n"((sc + 0) | (b << 8)), [idx1] "n"((sc + 1) | (b << 8)), [idx2] "n"((sc + 2) | (b << 8)), [idx3] "n"((sc + 3) | (b << 8))
+                                             : "memory");
+                                } else if constexpr (L2) { // (the 128 x 128 tile's accumulators are VGPRs: read in place)
+                                    asm volatile("v_fma_f32 %[t0], %[a0], -2.0, %[s0]\n\t"
+                                             "v_fma_f32 %[t1], %[a1], -2.0, %[s1]\n\t"
+                                             "v_fma_f32 %[t2], %[a2], -2.0, %[s2]\n\t"
+                                             "v_fma_f32 %[t3], %[a3], -2.0, %[s3]\n\t"
+                                             "v_cmp_le_f32_e64 %[m0], %[t0], %[thr]\n\t"
+                                             "v_cmp_le_f32_e64 %[m1], %[t1], %[thr]\n\t"
+                                             "v_cmp_le_f32_e64 %[m2], %[t2], %[thr]\n\t"
+                                             "v_cmp_le_f32_e64 %[m3], %[t3], %[thr]\n\t"
+                                             "v_min_u32_e32 %[ad0], %[w], %[dump]\n\t"
+                                             "v_cndmask_b32_e64 %[u], 0, %[step], %[m0]\n\t"
+                                             "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                             "v_min_u32_e32 %[ad1], %[w], %[dump]\n\t"
+                                             "v_cndmask_b32_e64 %[u], 0, %[step], %[m1]\n\t"
+                                             "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                             "v_min_u32_e32 %[ad2], %[w], %[dump]\n\t"
+                                             "v_cndmask_b32_e64 %[u], 0, %[step], %[m2]\n\t"
+                                             "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                             "v_min_u32_e32 %[ad3], %[w], %[dump]\n\t"
+                                             "v_cndmask_b32_e64 %[u], 0, %[step], %[m3]\n\t"
+                                             "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                             "v_mov_b32_e32 %[i0], %[idx0]\n\t"
+                                             "v_mov_b32_e32 %[i1], %[idx1]\n\t"
+                                             "v_mov_b32_e32 %[i2], %[idx2]\n\t"
+                                             "v_mov_b32_e32 %[i3], %[idx3]\n\t"
+                                             "ds_write2_b32 %[ad0], %[t0], %[i0] offset1:1\n\t"
+                                             "ds_write2_b32 %[ad1], %[t1], %[i1] offset1:1\n\t"
+                                             "ds_write2_b32 %[ad2], %[t2], %[i2] offset1:1\n\t"
+                                             "ds_write2_b32 %[ad3], %[t3], %[i3] offset1:1"
+                                             : [t0] "=&v"(t[0]), [t1] "=&v"(t[1]), [t2] "=&v"(t[2]), [t3] "=&v"(t[3]), [ad0] "=&v"(ad[0]), [ad1] "=&v"(ad[1]), [ad2] "=&v"(ad[2]), [ad3] "=&v"(ad[3]), [i0] "=&v"(ix[0]), [i1] "=&v"(ix[1]), [i2] "=&v"(ix[2]), [i3] "=&v"(ix[3]), [m0] "=&s"(mk[0]), [m1] "=&s"(mk[1]), [m2] "=&s"(mk[2]), [m3] "=&s"(mk[3]), [u] "=&v"(u), [w] "+v"(w)
+                                             : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [s0] "v"(s0), [s1] "v"(s1), [s2] "v"(s2), [s3] "v"(s3), [thr] "v"(thr[b]), [dump] "v"(dump), [step] "v"(step), [idx0] "n"((sc + 0) | (b << 8)), [idx1] "n"((sc + 1) | (b << 8)), [idx2] "n"((sc + 2) | (b << 8)), [idx3] "n"((sc + 3) | (b << 8))
+                                             : "memory");
+                                } else {
+                                    asm volatile("v_xor_b32_e32 %[t0], 0x80000000, %[a0]\n\t"
+                                             "v_xor_b32_e32 %[t1], 0x80000000, %[a1]\n\t"
+                                             "v_xor_b32_e32 %[t2], 0x80000000, %[a2]\n\t"
+                                             "v_xor_b32_e32 %[t3], 0x80000000, %[a3]\n\t"
+                                             "v_cmp_le_f32_e64 %[m0], %[t0], %[thr]\n\t"
+                                             "v_cmp_le_f32_e64 %[m1], %[t1], %[thr]\n\t"
+                                             "v_cmp_le_f32_e64 %[m2], %[t2], %[thr]\n\t"
+                                             "v_cmp_le_f32_e64 %[m3], %[t3], %[thr]\n\t"
+                                             "v_min_u32_e32 %[ad0], %[w], %[dump]\n\t"
+                                             "v_cndmask_b32_e64 %[u], 0, %[step], %[m0]\n\t"
+                                             "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                             "v_min_u32_e32 %[ad1], %[w], %[dump]\n\t"
+                                             "v_cndmask_b32_e64 %[u], 0, %[step], %[m1]\n\t"
+                                             "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                             "v_min_u32_e32 %[ad2], %[w], %[dump]\n\t"
+                                             "v_cndmask_b32_e64 %[u], 0, %[step], %[m2]\n\t"
+                                             "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                             "v_min_u32_e32 %[ad3], %[w], %[dump]\n\t"
+                                             "v_cndmask_b32_e64 %[u], 0, %[step], %[m3]\n\t"
+                                             "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                             "v_mov_b32_e32 %[i0], %[idx0]\n\t"
+                                             "v_mov_b32_e32 %[i1], %[idx1]\n\t"
+                                             "v_mov_b32_e32 %[i2], %[idx2]\n\t"
+                                             "v_mov_b32_e32 %[i3], %[idx3]\n\t"
+                                             "ds_write2_b32 %[ad0], %[t0], %[i0] offset1:1\n\t"
+                                             "ds_write2_b32 %[ad1], %[t1], %[i1] offset1:1\n\t"
+                                             "ds_write2_b32 %[ad2], %[t2], %[i2] offset1:1\n\t"
+                                             "ds_write2_b32 %[ad3], %[t3], %[i3] offset1:1"
+                                             : [t0] "=&v"(t[0]), [t1] "=&v"(t[1]), [t2] "=&v"(t[2]), [t3] "=&v"(t[3]), [ad0] "=&v"(ad[0]), [ad1] "=&v"(ad[1]), [ad2] "=&v"(ad[2]), [ad3] "=&v"(ad[3]), [i0] "=&v"(ix[0]), [i1] "=&v"(ix[1]), [i2] "=&v"(ix[2]), [i3] "=&v"(ix[3]), [m0] "=&s"(mk[0]), [m1] "=&s"(mk[1]), [m2] "=&s"(mk[2]), [m3] "=&s"(mk[3]), [u] "=&v"(u), [w] "+v"(w)
+                                             : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [thr] "v"(thr[b]), [dump] "v"(dump), [step] "v"(step), [idx0] "n"((sc + 0) | (b << 8)), [idx1] "n"((sc + 1) | (b << 8)), [idx2] "n"((sc + 2) | (b << 8)), [idx3] "n"((sc + 3) | (b << 8))
+                                             : "memory");
+                                }
+                            } else { // (the second direction: the same values decide for rows rowl(sc ..) as queries; a lane whose own query is no
+                                     // candidate -- past the end, or a row of the sample -- compares against -inf)
+                                if constexpr (BIGT && L2) {
+                                    asm volatile("v_accvgpr_read_b32 %[t0], %[a0]\n\t"
+                                             "v_accvgpr_read_b32 %[t1], %[a1]\n\t"
+                                             "v_accvgpr_read_b32 %[t2], %[a2]\n\t"
+                                             "v_accvgpr_read_b32 %[t3], %[a3]\n\t"
+                                             "v_fma_f32 %[t0], %[t0], -2.0, %[s0]\n\t"
+                                             "v_fma_f32 %[t1], %[t1], -2.0, %[s1]\n\t"
+                                             "v_fma_f32 %[t2], %[t2], -2.0, %[s2]\n\t"
+                                             "v_fma_f32 %[t3], %[t3], -2.0, %[s3]\n\t"
+                                             "v_cndmask_b32_e64 %[e0], %[ninf], %[h0], %[cok]\n\t"
                                              "v_cndmask_b32_e64 %[e1], %[ninf], %[h1], %[cok]\n\t"
                                              "v_cndmask_b32_e64 %[e2], %[ninf], %[h2], %[cok]\n\t"
                                              "v_cndmask_b32_e64 %[e3], %[ninf], %[h3], %[cok]\n\t"
@@ -1989,31 +2085,153 @@ __global__ __launch_bounds__(256, (TM * TN >= 16 ? 1 : 2)) void flat_scan_kernel
                                              "ds_write2_b32 %[ad1], %[t1], %[i1] offset1:1\n\t"
                                              "ds_write2_b32 %[ad2], %[t2], %[i2] offset1:1\n\t"
                                              "ds_write2_b32 %[ad3], %[t3], %[i3] offset1:1"
-                                             : [e0] "=&v"(e[0]), [e1] "=&v"(e[1]), [e2] "=&v"(e[2]), [e3] "=&v"(e[3]), [ad0] "=&v"(ad[0]), [ad1] "=&v"(ad[1]), [ad2] "=&v"(ad[2]), [ad3] "=&v"(ad[3]), [i0] "=&v"(ix[0]), [i1] "=&v"(ix[1]), [i2] "=&v"(ix[2]), [i3] "=&v"(ix[3]), [m0] "=&s"(mk[0]), [m1] "=&s"(mk[1]), [m2] "=&s"(mk[2]), [m3] "=&s"(mk[3]), [u] "=&v"(u), [w] "+v"(w2)
-                                             : [t0] "v"(t[0]), [t1] "v"(t[1]), [t2] "v"(t[2]), [t3] "v"(t[3]),
-                                               [h0] "v"(t2l[sc - c]), [h1] "v"(t2l[sc - c + 1]), [h2] "v"(t2l[sc - c + 2]), [h3] "v"(t2l[sc - c + 3]),
-                                               [ninf] "v"(ninf), [cok] "s"(cokm[b]), [dump] "v"(dump2), [step] "v"(step), [idx0] "n"((sc + 0) | (b << 8)), [idx1] "n"((sc + 1) | (b << 8)), [idx2] "n"((sc + 2) | (b << 8)), [idx3] "n"((sc + 3) | (b << 8))
+                                             : [t0] "=&v"(t[0]), [t1] "=&v"(t[1]), [t2] "=&v"(t[2]), [t3] "=&v"(t[3]), [ad0] "=&v"(ad[0]), [ad1] "=&v"(ad[1]), [ad2] "=&v"(ad[2]), [ad3] "=&v"(ad[3]), [i0] "=&v"(ix[0]), [i1] "=&v"(ix[1]), [i2] "=&v"(ix[2]), [i3] "=&v"(ix[3]), [m0] "=&s"(mk[0]), [m1] "=&s"(mk[1]), [m2] "=&s"(mk[2]), [m3] "=&s"(mk[3]), [u] "=&v"(u), [w] "+v"(w), [e0] "=&v"(e[0]), [e1] "=&v"(e[1]), [e2] "=&v"(e[2]), [e3] "=&v"(e[3])
+                                             : [a0] "a"(a0), [a1] "a"(a1), [a2] "a"(a2), [a3] "a"(a3), [s0] "v"(s0), [s1] "v"(s1), [s2] "v"(s2), [s3] "v"(s3), [h0] "v"(t2l[sc - c + 0]), [h1] "v"(t2l[sc - c + 1]), [h2] "v"(t2l[sc - c + 2]), [h3] "v"(t2l[sc - c + 3]), [ninf] "v"(ninf), [cok] "s"(cokm[b]), [dump] "v"(dump), [step] "v"(step), [idx0] "n"((sc + 0) | (b << 8)), [idx1] "n"((sc + 1) | (b << 8)), [idx2] "n"((sc + 2) | (b << 8)), [idx3] "n"((sc + 3) | (b << 8))
                                              : "memory");
+                                } else if constexpr (BIGT) {
+                                    asm volatile("v_accvgpr_read_b32 %[t0], %[a0]\n\t"
+                                             "v_accvgpr_read_b32 %[t1], %[a1]\n\t"
+                                             "v_accvgpr_read_b32 %[t2], %[a2]\n\t"
+                                             "v_accvgpr_read_b32 %[t3], %[a3]\n\t"
+                                             "v_xor_b32_e32 %[t0], 0x80000000, %[t0]\n\t"
+                                             "v_xor_b32_e32 %[t1], 0x80000000, %[t1]\n\t"
+                                             "v_xor_b32_e32 %[t2], 0x80000000, %[t2]\n\t"
+                                             "v_xor_b32_e32 %[t3], 0x80000000, %[t3]\n\t"
+                                             "v_cndmask_b32_e64 %[e0], %[ninf], %[h0], %[cok]\n\t"
+                                             "v_cndmask_b32_e64 %[e1], %[ninf], %[h1], %[cok]\n\t"
+                                             "v_cndmask_b32_e64 %[e2], %[ninf], %[h2], %[cok]\n\t"
+                                             "v_cndmask_b32_e64 %[e3], %[ninf], %[h3], %[cok]\n\t"
+                                             "v_cmp_le_f32_e64 %[m0], %[t0], %[e0]\n\t"
+                                             "v_cmp_le_f32_e64 %[m1], %[t1], %[e1]\n\t"
+                                             "v_cmp_le_f32_e64 %[m2], %[t2], %[e2]\n\t"
+                                             "v_cmp_le_f32_e64 %[m3], %[t3], %[e3]\n\t"
+                                             "v_min_u32_e32 %[ad0], %[w], %[dump]\n\t"
+                                             "v_cndmask_b32_e64 %[u], 0, %[step], %[m0]\n\t"
+                                             "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                             "v_min_u32_e32 %[ad1], %[w], %[dump]\n\t"
+                                             "v_cndmask_b32_e64 %[u], 0, %[step], %[m1]\n\t"
+                                             "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                             "v_min_u32_e32 %[ad2], %[w], %[dump]\n\t"
+                                             "v_cndmask_b32_e64 %[u], 0, %[step], %[m2]\n\t"
+                                             "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                             "v_min_u32_e32 %[ad3], %[w], %[dump]\n\t"
+                                             "v_cndmask_b32_e64 %[u], 0, %[step], %[m3]\n\t"
+                                             "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                             "v_mov_b32_e32 %[i0], %[idx0]\n\t"
+                                             "v_mov_b32_e32 %[i1], %[idx1]\n\t"
+                                             "v_mov_b32_e32 %[i2], %[idx2]\n\t"
+                                             "v_mov_b32_e32 %[i3], %[idx3]\n\t"
+                                             "ds_write2_b32 %[ad0], %[t0], %[i0] offset1:1\n\t"
+                                             "ds_write2_b32 %[ad1], %[t1], %[i1] offset1:1\n\t"
+                                             "ds_write2_b32 %[ad2], %[t2], %[i2] offset1:1\n\t"
+                                             "ds_write2_b32 %[ad3], %[t3], %[i3] offset1:1"
+                                             : [t0] "=&v"(t[0]), [t1] "=&v"(t[1]), [t2] "=&v"(t[2]), [t3] "=&v"(t[3]), [ad0] "=&v"(ad[0]), [ad1] "=&v"(ad[1]), [ad2] "=&v"(ad[2]), [ad3] "=&v"(ad[3]), [i0] "=&v"(ix[0]), [i1] "=&v"(ix[1]), [i2] "=&v"(ix[2]), [i3] "=&v"(ix[3]), [m0] "=&s"(mk[0]), [m1] "=&s"(mk[1]), [m2] "=&s"(mk[2]), [m3] "=&s"(mk[3]), [u] "=&v"(u), [w] "+v"(w), [e0] "=&v"(e[0]), [e1] "=&v"(e[1]), [e2] "=&v"(e[2]), [e3] "=&v"(e[3])
+                                             : [a0] "a"(a0), [a1] "a"(a1), [a2] "a"(a2), [a3] "a"(a3), [h0] "v"(t2l[sc - c + 0]), [h1] "v"(t2l[sc - c + 1]), [h2] "v"(t2l[sc - c + 2]), [h3] "v"(t2l[sc - c + 3]), [ninf] "v"(ninf), [cok] "s"(cokm[b]), [dump] "v"(dump), [step] "v"(step), [idx0] "n"((sc + 0) | (b << 8)), [idx1] "n"((sc + 1) | (b << 8)), [idx2] "n"((sc + 2) | (b << 8)), [idx3] "n"((sc + 3) | (b << 8))
+                                             : "memory");
+                                } else if constexpr (L2) { // (the 128 x 128 tile's accumulators are VGPRs: read in place)
+                                    asm volatile("v_fma_f32 %[t0], %[a0], -2.0, %[s0]\n\t"
+                                             "v_fma_f32 %[t1], %[a1], -2.0, %[s1]\n\t"
+                                             "v_fma_f32 %[t2], %[a2], -2.0, %[s2]\n\t"
+                                             "v_fma_f32 %[t3], %[a3], -2.0, %[s3]\n\t"
+                                             "v_cndmask_b32_e64 %[e0], %[ninf], %[h0], %[cok]\n\t"
+                                             "v_cndmask_b32_e64 %[e1], %[ninf], %[h1], %[cok]\n\t"
+                                             "v_cndmask_b32_e64 %[e2], %[ninf], %[h2], %[cok]\n\t"
+                                             "v_cndmask_b32_e64 %[e3], %[ninf], %[h3], %[cok]\n\t"
+                                             "v_cmp_le_f32_e64 %[m0], %[t0], %[e0]\n\t"
+                                             "v_cmp_le_f32_e64 %[m1], %[t1], %[e1]\n\t"
+                                             "v_cmp_le_f32_e64 %[m2], %[t2], %[e2]\n\t"
+                                             "v_cmp_le_f32_e64 %[m3], %[t3], %[e3]\n\t"
+                                             "v_min_u32_e32 %[ad0], %[w], %[dump]\n\t"
+                                             "v_cndmask_b32_e64 %[u], 0, %[step], %[m0]\n\t"
+                                             "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                             "v_min_u32_e32 %[ad1], %[w], %[dump]\n\t"
+                                             "v_cndmask_b32_e64 %[u], 0, %[step], %[m1]\n\t"
+                                             "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                             "v_min_u32_e32 %[ad2], %[w], %[dump]\n\t"
+                                             "v_cndmask_b32_e64 %[u], 0, %[step], %[m2]\n\t"
+                                             "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                             "v_min_u32_e32 %[ad3], %[w], %[dump]\n\t"
+                                             "v_cndmask_b32_e64 %[u], 0, %[step], %[m3]\n\t"
+                                             "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                             "v_mov_b32_e32 %[i0], %[idx0]\n\t"
+                                             "v_mov_b32_e32 %[i1], %[idx1]\n\t"
+                                             "v_mov_b32_e32 %[i2], %[idx2]\n\t"
+                                             "v_mov_b32_e32 %[i3], %[idx3]\n\t"
+                                             "ds_write2_b32 %[ad0], %[t0], %[i0] offset1:1\n\t"
+                                             "ds_write2_b32 %[ad1], %[t1], %[i1] offset1:1\n\t"
+                                             "ds_write2_b32 %[ad2], %[t2], %[i2] offset1:1\n\t"
+                                             "ds_write2_b32 %[ad3], %[t3], %[i3] offset1:1"
+                                             : [t0] "=&v"(t[0]), [t1] "=&v"(t[1]), [t2] "=&v"(t[2]), [t3] "=&v"(t[3]), [ad0] "=&v"(ad[0]), [ad1] "=&v"(ad[1]), [ad2] "=&v"(ad[2]), [ad3] "=&v"(ad[3]), [i0] "=&v"(ix[0]), [i1] "=&v"(ix[1]), [i2] "=&v"(ix[2]), [i3] "=&v"(ix[3]), [m0] "=&s"(mk[0]), [m1] "=&s"(mk[1]), [m2] "=&s"(mk[2]), [m3] "=&s"(mk[3]), [u] "=&v"(u), [w] "+v"(w), [e0] "=&v"(e[0]), [e1] "=&v"(e[1]), [e2] "=&v"(e[2]), [e3] "=&v"(e[3])
+                                             : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [s0] "v"(s0), [s1] "v"(s1), [s2] "v"(s2), [s3] "v"(s3), [h0] "v"(t2l[sc - c + 0]), [h1] "v"(t2l[sc - c + 1]), [h2] "v"(t2l[sc - c + 2]), [h3] "v"(t2l[sc - c + 3]), [ninf] "v"(ninf), [cok] "s"(cokm[b]), [dump] "v"(dump), [step] "v"(step), [idx0] "n"((sc + 0) | (b << 8)), [idx1] "n"((sc + 1) | (b << 8)), [idx2] "n"((sc + 2) | (b << 8)), [idx3] "n"((sc + 3) | (b << 8))
+                                             : "memory");
+                                } else {
+                                    asm volatile("v_xor_b32_e32 %[t0], 0x80000000, %[a0]\n\t"
+                                             "v_xor_b32_e32 %[t1], 0x80000000, %[a1]\n\t"
+                                             "v_xor_b32_e32 %[t2], 0x80000000, %[a2]\n\t"
+                                             "v_xor_b32_e32 %[t3], 0x80000000, %[a3]\n\t"
+                                             "v_cndmask_b32_e64 %[e0], %[ninf], %[h0], %[cok]\n\t"
+                                             "v_cndmask_b32_e64 %[e1], %[ninf], %[h1], %[cok]\n\t"
+                                             "v_cndmask_b32_e64 %[e2], %[ninf], %[h2], %[cok]\n\t"
+                                             "v_cndmask_b32_e64 %[e3], %[ninf], %[h3], %[cok]\n\t"
+                                             "v_cmp_le_f32_e64 %[m0], %[t0], %[e0]\n\t"
+                                             "v_cmp_le_f32_e64 %[m1], %[t1], %[e1]\n\t"
+                                             "v_cmp_le_f32_e64 %[m2], %[t2], %[e2]\n\t"
+                                             "v_cmp_le_f32_e64 %[m3], %[t3], %[e3]\n\t"
+                                             "v_min_u32_e32 %[ad0], %[w], %[dump]\n\t"
+                                             "v_cndmask_b32_e64 %[u], 0, %[step], %[m0]\n\t"
+                                             "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                             "v_min_u32_e32 %[ad1], %[w], %[dump]\n\t"
+                                             "v_cndmask_b32_e64 %[u], 0, %[step], %[m1]\n\t"
+                                             "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                             "v_min_u32_e32 %[ad2], %[w], %[dump]\n\t"
+                                             "v_cndmask_b32_e64 %[u], 0, %[step], %[m2]\n\t"
+                                             "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                             "v_min_u32_e32 %[ad3], %[w], %[dump]\n\t"
+                                             "v_cndmask_b32_e64 %[u], 0, %[step], %[m3]\n\t"
+                                             "v_add_u32_e32 %[w], %[w], %[u]\n\t"
+                                             "v_mov_b32_e32 %[i0], %[idx0]\n\t"
+                                             "v_mov_b32_e32 %[i1], %[idx1]\n\t"
+                                             "v_mov_b32_e32 %[i2], %[idx2]\n\t"
+                                             "v_mov_b32_e32 %[i3], %[idx3]\n\t"
+                                             "ds_write2_b32 %[ad0], %[t0], %[i0] offset1:1\n\t"
+                                             "ds_write2_b32 %[ad1], %[t1], %[i1] offset1:1\n\t"
+                                             "ds_write2_b32 %[ad2], %[t2], %[i2] offset1:1\n\t"
+                                             "ds_write2_b32 %[ad3], %[t3], %[i3] offset1:1"
+                                             : [t0] "=&v"(t[0]), [t1] "=&v"(t[1]), [t2] "=&v"(t[2]), [t3] "=&v"(t[3]), [ad0] "=&v"(ad[0]), [ad1] "=&v"(ad[1]), [ad2] "=&v"(ad[2]), [ad3] "=&v"(ad[3]), [i0] "=&v"(ix[0]), [i1] "=&v"(ix[1]), [i2] "=&v"(ix[2]), [i3] "=&v"(ix[3]), [m0] "=&s"(mk[0]), [m1] "=&s"(mk[1]), [m2] "=&s"(mk[2]), [m3] "=&s"(mk[3]), [u] "=&v"(u), [w] "+v"(w), [e0] "=&v"(e[0]), [e1] "=&v"(e[1]), [e2] "=&v"(e[2]), [e3] "=&v"(e[3])
+                                             : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [h0] "v"(t2l[sc - c + 0]), [h1] "v"(t2l[sc - c + 1]), [h2] "v"(t2l[sc - c + 2]), [h3] "v"(t2l[sc - c + 3]), [ninf] "v"(ninf), [cok] "s"(cokm[b]), [dump] "v"(dump), [step] "v"(step), [idx0] "n"((sc + 0) | (b << 8)), [idx1] "n"((sc + 1) | (b << 8)), [idx2] "n"((sc + 2) | (b << 8)), [idx3] "n"((sc + 3) | (b << 8))
+                                             : "memory");
+                                }
                             }
                         }
+                        if constexpr (DIR == 1) nblk[b] += w - w_b;
                     }
-                    nblk[b] += w1 - w1_b;
-                }
                 }
             };
-            if (SYM && second) pass1(std::true_type{});
-            else pass1(std::false_type{});
+            pass1(std::integral_constant<int, 1>{});
+            const uint32_t w1 = w, w1_0 = w_0;
             KNN_TRACE_AT(tile_idx == 5, 126);
-            const int n1 = (int)((w1 - w1_0) >> 11), n2 = (int)((w2 - w2_0) >> 11);
+            const int n1 = (int)((w1 - w1_0) >> 11);
             // ---- first direction: this wave's survivors -> the queries' lists
-            if (__ballot(n1 > C1) != 0ull) {
+            KNN_TRACE_COUNT(__ballot(n1 > C) != 0ull, 60); // (developer build: tiles wave 0 filtered the dense way; slot 59: tiles whose second direction went dense; 58: the wave's largest n1)
+#ifdef KNN355_TRACE
+            if (p.trace) { // (developer build: the workgroup's largest per-lane survivor counts, first / second direction)
+                atomicMax((unsigned long long *)&p.trace[(size_t)blockIdx.x * 128 + 58], (unsigned long long)n1);
+            }
+#endif
+            if (__ballot(n1 > C) != 0ull) {
                 filter_tile(trow0, passes_acc, score_of); // (a lane ran out of slots: the dense way, from the accumulators)
             } else {
-                // One reservation per lane and query block -- four LDS atomics, in flight together -- then the entries four per
-                // round: LDS reads and stores only.  (One atomic per entry and one entry per round: 4.8 us per tile at k = 100, 12.4
-                // at k = 1000, each round a chain of three dependent round trips; four entries per round: 2.9 / 7.6.)
+                // One reservation per lane and query block (LDS atomics) and the lane's first U1 entries, all requested together and
+                // waited for ONCE, then stores only; a lane with more entries goes round again.  (Beside the other workgroup's K loop
+                // a wave that waits gets back in slowly -- per-workgroup stamps of a CATH-sized symmetric tile: pass 1, straight-line,
+                // 1.6 us; this pass with four entries per round and the reservations in front, five waits: 10 us -- so what counts here
+                // is the number of waits, not of instructions.)
+                constexpr int U1 = 8;
                 bool near_full = false;
                 int base[NB], run[NB];
+                uint2 e[U1];
+#pragma unroll
+                for (int u = 0; u < U1; u++) e[u] = *(const uint2 *)(smem + OFF1 + (min(u, C) * 256 + tid) * 8);
 #pragma unroll
                 for (int b = 0; b < NB; b++) {
                     const int cnt = (int)(nblk[b] >> 11);
@@ -2021,17 +2239,17 @@ __global__ __launch_bounds__(256, (TM * TN >= 16 ? 1 : 2)) void flat_scan_kernel
                     run[b] = 0;
                     near_full |= cnt > 0 && base[b] + cnt > L.cap - DT;
                 }
-                for (int j0 = 0; __ballot(j0 < n1) != 0ull; j0 += 4) {
-                    uint2 e[4];
+                for (int j0 = 0;;) {
 #pragma unroll
-                    for (int u = 0; u < 4; u++) e[u] = *(const uint2 *)(smem + OFF1 + (min(j0 + u, C1) * 256 + tid) * 8);
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
+                    for (int u = 0; u < U1; u++) {
                         if (j0 + u < n1) {
                             const int b = (int)((e[u].y >> 8) & 3u);
-                            // (b is a runtime number: the block's base and running count picked out of four registers each)
-                            const int slot = (b == 0 ? base[0] + run[0] : b == 1 ? base[1] + run[1] : b == 2 ? base[2] + run[2] : base[3] + run[3]);
-                            run[0] += b == 0; run[1] += b == 1; run[2] += b == 2; run[3] += b == 3;
+                            // (b is a runtime number: the block's base and running count picked out of NB registers each)
+                            int slot = base[0] + run[0];
+#pragma unroll
+                            for (int bb = 1; bb < NB; bb++) slot = b == bb ? base[bb] + run[bb] : slot;
+#pragma unroll
+                            for (int bb = 0; bb < NB; bb++) run[bb] += b == bb;
                             const int ql = (wn * TN + b) * 32 + li;
                             float vv = __uint_as_float(e[u].x);
                             if constexpr (L2) vv = vv < 0.0f ? 0.0f : vv;
@@ -2042,6 +2260,10 @@ __global__ __launch_bounds__(256, (TM * TN >= 16 ? 1 : 2)) void flat_scan_kernel
                             if (slot < L.cap) L.lists[(size_t)ql * L.cap + slot] = gone ? KEY_PAD : (((uint64_t)f2ord(vv) << 32) | id);
                         }
                     }
+                    j0 += U1;
+                    if (__ballot(j0 < n1) == 0ull) break;
+#pragma unroll
+                    for (int u = 0; u < U1; u++) e[u] = *(const uint2 *)(smem + OFF1 + (min(j0 + u, C) * 256 + tid) * 8);
                 }
                 if (near_full) *L.s_need = 1;
             }
@@ -2049,44 +2271,80 @@ __global__ __launch_bounds__(256, (TM * TN >= 16 ? 1 : 2)) void flat_scan_kernel
             // ---- second direction (symmetric launch, off the diagonal): the rows of this tile as queries
             if constexpr (SYM) {
                 if (!second) return; // (workgroup-uniform: the diagonal tile)
-                if (n2 > C2) *s_dense = 1;
+                // pass 1 again, with the rows' bounds, into the same slots (this lane's own: the first direction is through with them)
+                w = w_0;
+                pass1(std::integral_constant<int, 2>{});
+                const int n2 = (int)((w - w_0) >> 11);
+                if (n2 > C) *s_dense = 1;
                 __syncthreads();
                 const bool dense = *s_dense != 0;
+                KNN_TRACE_AT(tile_idx == 5, 120);
+                KNN_TRACE_COUNT(dense, 59);
+#ifdef KNN355_TRACE
+                if (p.trace) atomicMax((unsigned long long *)&p.trace[(size_t)blockIdx.x * 128 + 57], (unsigned long long)n2);
+#endif
                 *dense2 = dense;
                 if (dense) return; // (the flag is cleared at the start of the next tile)
-                // ranks inside each row's survivors of this tile
-                for (int j0 = 0; j0 < n2; j0 += 4) { // (four reservations in flight)
+                // Ranks inside each row's survivors of this tile (LDS atomics), one global reservation per row, then the stores.
+                // A lane's first U2 entries stay in REGISTERS from the rank phase to the stores, a lane with more takes the rest
+                // through its LDS slots, four at a time.  (First form: every entry read from LDS in both phases, four entries per
+                // round in the rank phase and one in the store phase -- 24 + 16 us of a CATH-sized symmetric tile's 59-us epilogue:
+                // a dozen waits and a few dozen, beside the other workgroup's K loop.)
+                constexpr int U2 = 16;
+                uint2 g[U2];
+                int rk[U2];
+#pragma unroll
+                for (int u = 0; u < U2; u++) g[u] = *(const uint2 *)(smem + OFF1 + (min(u, C) * 256 + tid) * 8);
+#pragma unroll
+                for (int u = 0; u < U2; u++) rk[u] = atomicAdd(&s_cnt2[rowl((int)(g[u].y & 63u))], u < n2 ? 1 : 0);
+                for (int j0 = U2; j0 < n2; j0 += 4) { // (the entries past the registers: rank written back into the slot)
                     uint32_t *yp[4], y[4];
-                    int rk[4];
+                    int r4[4];
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
-                        yp[u] = (uint32_t *)(smem + OFF2 + (min(j0 + u, C2) * 256 + tid) * 8 + 4);
+                        yp[u] = (uint32_t *)(smem + OFF1 + (min(j0 + u, C) * 256 + tid) * 8 + 4);
                         y[u] = *yp[u];
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; u++) rk[u] = atomicAdd(&s_cnt2[rowl((int)(y[u] & 63u))], j0 + u < n2 ? 1 : 0);
+                    for (int u = 0; u < 4; u++) r4[u] = atomicAdd(&s_cnt2[rowl((int)(y[u] & 63u))], j0 + u < n2 ? 1 : 0);
 #pragma unroll
                     for (int u = 0; u < 4; u++)
-                        if (j0 + u < n2) *yp[u] = y[u] | ((unsigned)rk[u] << 16);
+                        if (j0 + u < n2) *yp[u] = y[u] | ((unsigned)r4[u] << 16);
                 }
                 __syncthreads();
+                KNN_TRACE_AT(tile_idx == 5, 121);
                 if (tid < DT) {
                     const int c = s_cnt2[tid];
+#ifdef KNN355_TRACE
+                    if (p.ablate & 64) s_base2[tid] = 0; // (developer build: without the global reservation -- wrong places, right time)
+                    else
+#endif
                     s_base2[tid] = c > 0 ? (int)atomicAdd(&p.qcnt[trow0 + tid], (uint32_t)c) : 0;
                     s_cnt2[tid] = 0; // (for the next tile)
                 }
                 __syncthreads();
-                for (int j = 0; j < n2; j++) {
-                    const uint2 e = *(const uint2 *)(smem + OFF2 + (j * 256 + tid) * 8);
-                    const int sc = (int)(e.y & 255u), b = (int)((e.y >> 8) & 255u), rank = (int)(e.y >> 16);
+                KNN_TRACE_AT(tile_idx == 5, 122);
+                auto put = [&](float value, int sc, int b, int at_in_row) { // (b is a runtime number: the lane's query of block b, spelled out)
                     const int rl = rowl(sc);
-                    float vv = __uint_as_float(e.x);
+                    float vv = value;
                     if constexpr (L2) vv = vv < 0.0f ? 0.0f : vv;
-                    const int at = s_base2[rl] + rank;
-                    // (b is a runtime number here: the lane's query of block b, spelled out)
                     const uint32_t id = p.id_base + (uint32_t)(q0 + (wn * TN + b) * 32 + li);
-                    if (at < p.qcap) p.qlist[(size_t)(trow0 + rl) * p.qcap + at] = ((uint64_t)f2ord(vv + 0.0f) << 32) | id;
+                    if (at_in_row < p.qcap) p.qlist[(size_t)(trow0 + rl) * p.qcap + at_in_row] = ((uint64_t)f2ord(vv + 0.0f) << 32) | id;
                     else *p.fail = 1;
+                };
+                int bs[U2];
+#pragma unroll
+                for (int u = 0; u < U2; u++) bs[u] = s_base2[rowl((int)(g[u].y & 63u))];
+#ifdef KNN355_TRACE
+                if (p.ablate & 256) return; // (developer build: without the stores)
+#endif
+#pragma unroll
+                for (int u = 0; u < U2; u++)
+                    if (u < n2) put(__uint_as_float(g[u].x), (int)(g[u].y & 255u), (int)((g[u].y >> 8) & 3u), bs[u] + rk[u]);
+                for (int j = U2; j < n2; j++) {
+                    const uint2 e = *(const uint2 *)(smem + OFF1 + (j * 256 + tid) * 8);
+                    const int sc = (int)(e.y & 255u);
+                    put(__uint_as_float(e.x), sc, (int)((e.y >> 8) & 3u), s_base2[rowl(sc)] + (int)(e.y >> 16));
                 }
             }
         };
@@ -2103,12 +2361,13 @@ __global__ __launch_bounds__(256, (TM * TN >= 16 ? 1 : 2)) void flat_scan_kernel
         if (!(p.ablate & 1))
 #endif
         {
-            if constexpr (TM * TN >= 16) {
+            if constexpr (SPARSE) {
                 // The next tile's first K step goes out NOW, into buffer 0: behind the K loop's last barrier no wave reads a
                 // staging buffer any more (the last sub-step runs from registers), the epilogue below keeps its slots in
                 // buffer 1, and its ~8 us cover the bytes' way from L2 / HBM -- the tile prologue found them exposed (2-3 us
                 // per tile with nothing else on the CU).
-                if (next_tile >= 0) {
+                if constexpr (!BIGT) __syncthreads(); // (the generic K loop's last step reads its fragments from LDS: every wave is through before the slots below are written)
+                if (BIGT && next_tile >= 0) {
                     const int64_t nrow0 = (int64_t)next_tile * DT;
 #pragma unroll
                     for (int n = 0; n < NI; n++) {
@@ -2224,9 +2483,11 @@ __global__ __launch_bounds__(256, (TM * TN >= 16 ? 1 : 2)) void flat_scan_kernel
         const bool last_tile = next_tile < 0;
         if (*L.s_need || last_tile) lists_compact<QT>(L, smem, DT, last_tile, tid);
         KNN_TRACE(2 + 2 * tile_idx);
+        if constexpr (!BIGT && KNN355_EPI_PRIO > 0) __builtin_amdgcn_s_setprio(0);
         cur_tile = next_tile;
         tile_idx++;
     }
+    if constexpr (!BIGT && KNN355_EPI_PRIO > 0) __builtin_amdgcn_s_setprio(KNN355_EPI_PRIO); // (the flush is epilogue work too)
     lists_flush<QT>(L, s_base, q0, p.nq, p.qlist, p.qcnt, p.qcap, tid, SYM ? p.fail : nullptr);
     KNN_TRACE(63);
 }
@@ -4210,7 +4471,9 @@ static int self_search_symmetric(knn_index_s *h, int k, float *D_dev, int64_t *I
         HIP_TRY(hipMemsetAsync(h->ws_turn.p, 0, 2048 * 4, s));
         p.cu_turn = (uint32_t *)h->ws_turn.p;
     }
-    const size_t lds = pl.lds + (size_t)(2 + 2) * pl.dt * 4; // + thresholds, per-half counts and bases of the tile's rows
+    // + thresholds, per-half counts and bases of the tile's rows (+ 8 KB of slots for the 128-row tile's sparse epilogue, see lds_main in the kernel)
+    const size_t lds = pl.lds + (size_t)(2 + 2) * pl.dt * 4 + (TS == 128 ? (size_t)73728 - std::max((size_t)2 * (pl.dt + pl.qt) * 128, (size_t)pl.cap * 8) : 0)
+                       + (size_t)dev_knob("KNN355_LDS_PAD", 0); // (developer build: more LDS than a second workgroup leaves room for = one workgroup per CU)
     void (*kern)(ScanParams) = h->metric == KNN_METRIC_L2 ? flat_scan_kernel<2, 2, 2, 2, true, false, true> : flat_scan_kernel<2, 2, 2, 2, false, false, true>;
     if (TS == 256) kern = h->metric == KNN_METRIC_L2 ? flat_scan_kernel<2, 2, 4, 4, true, false, true> : flat_scan_kernel<2, 2, 4, 4, false, false, true>;
     HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
