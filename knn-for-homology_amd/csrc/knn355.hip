@@ -704,6 +704,10 @@ struct ScanParams {
     int npairs;
     int pool_tiles;     // the last pool_tiles tiles of every pair's range belong to a pool shared by ALL workgroups
     uint32_t *cu_turn;  // [2048] batch launches: one word per CU -- the two resident workgroups take turns in their K loops; NULL: off
+    int sparse_epi;     // 128 x 128 batch builds: filter the tiles through the sparse epilogue (thresholds that let a percent of the
+                        // scores pass: statistical seed, no seed) instead of filter_tile (exactly seeded scans: almost nothing passes,
+                        // its wave-wide early-outs cost next to nothing; the sparse epilogue's fixed 2 us per tile cost a 10 M-row
+                        // scan of 1024 queries 4 %)
 #ifdef KNN355_TRACE
     int ablate;                // developer build: 1 = skip the filter, 2 = masks only (no reservations / stores), 4 = wait for the accumulators before the stamp
     unsigned long long *trace; // developer build: [grid][128] wall-clock stamps (100 MHz) of each workgroup's progress (64.. : inside the epilogue)
@@ -1478,7 +1482,11 @@ __global__ __launch_bounds__(256, (TM * TN >= 16 ? 1 : 2)) void flat_scan_kernel
             // Every sub-step issues one MFMA, then the fragment reads of the next sub-step: the compiler waits lgkmcnt(0) in front
             // of a sub-step's first MFMA, and with the reads behind that MFMA the wait only ever covers reads a sub-step old.
             constexpr int MS = 4 * TM * TN;                        // MFMAs per sub-step
-            constexpr int NA = NI / 3, NBg = NI / 3, NC = NI - NA - NBg; // staging instructions per group
+            // staging instructions per group: half of K step kt + 1's in sub-step 3 of step kt - 1 (C), half in sub-step 0 of step kt
+            // (A), none in sub-step 1 (B) -- two whole sub-steps (3.7 us) for the bytes to land before the wait in front of the
+            // barrier.  (Thirds, the last of them with one sub-step of lead: fine while the rows come from L2 / the Infinity Cache
+            // -- a Pfam-sized index -- and 5 % slower than the 128 x 128 tile on a 10 M-row index, whose rows come from HBM.)
+            constexpr int NA = NI / 2, NBg = 0, NC = NI - NA - NBg;
 #ifdef KNN355_TRACE
             // (developer build: K loop without its staging instructions / its barrier / its fragment reads -- wrong scores, right time)
             const bool stage_on = !(p.ablate & 16), barrier_on = !(p.ablate & 32), reads_on = !(p.ablate & 128);
@@ -2361,7 +2369,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 16 ? 1 : 2)) void flat_scan_kernel
         if (!(p.ablate & 1))
 #endif
         {
-            if constexpr (SPARSE) {
+            if (SPARSE && (BIGT || SYM || p.sparse_epi)) {
                 // The next tile's first K step goes out NOW, into buffer 0: behind the K loop's last barrier no wave reads a
                 // staging buffer any more (the last sub-step runs from registers), the epilogue below keeps its slots in
                 // buffer 1, and its ~8 us cover the bytes' way from L2 / HBM -- the tile prologue found them exposed (2-3 us
@@ -2376,7 +2384,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 16 ? 1 : 2)) void flat_scan_kernel
                     }
                     staged0 = true;
                 }
-                sparse_epilogue(row0, off_diag, &dir2_dense);
+                if constexpr (SPARSE) sparse_epilogue(row0, off_diag, &dir2_dense);
             } else if (!deferred) filter_tile(row0, passes_acc, score_of);
         }
         KNN_TRACE(64 + 2 * tile_idx);
@@ -4028,6 +4036,7 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     p.vshift = sstride ? svshift : vshift;
     p.skip_mask = sstride ? sstride - 1 : -1;
     p.kslot = kslot;
+    p.sparse_epi = !(sstride && !seed_stat) && !pub_rounds; // (not exactly seeded: a statistical estimate, or no seed at all)
     p.pub = pub_rounds ? (uint64_t *)lb.pub.p : nullptr;
     p.arrive = pub_rounds ? (uint32_t *)lb.arrive.p : nullptr;
     p.pub_rounds = pub_rounds;
