@@ -363,6 +363,7 @@ def run(args):
     del warm
     progress("warmup_done")
     index.collective_events = [] if use_pg else None  # HIP event pairs around every all-gather of the timed steps
+    index.step_events = []  # a timing event behind every timed search: per-step durations (median beside the mean)
     pend = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -370,6 +371,11 @@ def run(args):
     fence()
     elapsed = time.perf_counter() - t0
     progress("timed_steps_done")
+    step_ms = None
+    if index.step_events and len(index.step_events) >= 3:
+        evs = index.step_events
+        step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(len(evs) - 1))  # (completion to completion, K - 1 values)
+    index.step_events = None
     for pnd in pend:  # (outside the timed region: the status rows of the K searches)
         pnd.check()
     D, I = pend[-1].result()
@@ -448,6 +454,10 @@ def run(args):
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
+        "ms_per_step_median": (step_ms[len(step_ms) // 2] if step_ms else None),
+        "ms_per_step_spread": ({"min": step_ms[0], "p90": step_ms[int(0.9 * (len(step_ms) - 1))], "max": step_ms[-1],
+                                "what": "HIP events behind consecutive timed searches, completion to completion (rank 0); `ms_per_step` "
+                                        "and `value` are the mean over the timed region as the driver's contract defines them"} if step_ms else None),
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
@@ -544,9 +554,46 @@ def run(args):
             out["batch"] = batch_config(dev, L, _lib, faiss)
         if not args.no_extras:
             out["hnsw"] = hnsw_config(dev, L, _lib, faiss)
+        rd = real_data()
+        if rd:
+            out["real_data"] = rd
     if use_pg:
         dist.destroy_process_group()
     return json.dumps(out)
+
+
+def real_data():
+    """SURVEY 8(d), opportunistic and never required: if the reference's embedding files are on this box (paths.py resolves
+    cath/data and pfam/full_sequences_data from $KNN355_PROJECT_ROOT / the git checkout / the current directory), the
+    reference's own calls on them -- cath/search.py:13-26 on every *.npy of cath/data (k = 10 + self, cosine), the flat mode of
+    pfam/proteins_search.py:49 on full_sequences.npy (k = 1000, cosine) -- timed end to end from numpy arrays."""
+    try:
+        from knn_for_homology_amd import paths
+        from knn_for_homology_amd.cath import search as cath_search
+        out = {}
+        d = paths.cath_data()
+        for npy in (sorted(d.glob("*.npy"))[:4] if d.is_dir() else []):
+            x = np.load(npy).astype(np.float32)
+            cath_search.search(x[: min(len(x), 2048)], hits=10)  # (warm-up)
+            t0 = time.perf_counter()
+            hits, scores = cath_search.search(x, hits=10)
+            out[f"cath/data/{npy.name}"] = {"shape": list(x.shape), "hits": 10, "metric": "cosine", "s": time.perf_counter() - t0,
+                                            "self_hit_dropped": bool((hits != np.arange(len(x))[:, None]).all())}
+        f = paths.full_sequences_data() / "full_sequences.npy"
+        if not f.is_file():
+            f = paths.pfam_dir() / "full_sequences.npy"
+        if f.is_file():
+            from knn_for_homology_amd import faiss as kfaiss
+            x = np.load(f).astype(np.float32)
+            kfaiss.normalize_L2(x)
+            t0 = time.perf_counter()
+            idx = kfaiss.IndexFlat(x.shape[1], kfaiss.METRIC_INNER_PRODUCT)
+            idx.add(x)
+            D, I = idx.search(x, min(1000, len(x)))
+            out[str(f.relative_to(paths.project_root()))] = {"shape": list(x.shape), "k": int(D.shape[1]), "metric": "cosine", "s": time.perf_counter() - t0}
+        return out or None
+    except Exception as e:  # noqa: BLE001 -- an extra: never a reason to lose the bench line
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def kernel_source_sha256():
@@ -1025,7 +1072,8 @@ def hnsw_replicas(dev, L, _lib, faiss, rank, world, dist):
     self_first = float((I[:, 0] >= 0).mean())
     del idx, x
     torch.cuda.empty_cache()
-    return {"workload": f"BASELINE configs[4] as {world} replicas: 200000x1024 clustered, IP, HNSW M=32 efSearch=256, k=100, {nq} queries per rank",
+    return {"workload": f"BASELINE configs[4] as {world} replicas: 200000x1024 clustered, IP, HNSW M=32 efSearch=256, k=100, {nq} queries per rank "
+                        "(bf16 beam, fp32 re-score)",
             "queries_per_s": world * nq / tmed, "build_s_rank0": build_s, "ms": 1e3 * tmed, "results_found_rank0": self_first}
 
 
@@ -1061,7 +1109,8 @@ def hnsw_config(dev, L, _lib, faiss):
         ts.append(time.perf_counter() - t0)
     t = float(np.median(ts))
     recall = float(np.mean([len(np.intersect1d(a[a >= 0], b)) for a, b in zip(Ih, It)])) / k
-    out = {"workload": "BASELINE configs[4]: 200000x1024 clustered (2000 centres + 0.35 noise), IP, HNSW M=32 efConstruction=40 efSearch=256, k=100",
+    out = {"workload": "BASELINE configs[4]: 200000x1024 clustered (2000 centres + 0.35 noise), IP, HNSW M=32 efConstruction=40 efSearch=256, k=100; "
+                       "the beam walks on bf16 copies of the rows (fp32 accumulation), every returned distance is re-scored in fp32 by the flat search's chain",
            "build_s": build_s, "queries_per_s": nq / t, "recall_at_100_vs_flat": recall, "nq": nq,
            "flat_queries_per_s_same_queries": nq / t_flat, "note": "host numpy in/out for both (IndexHNSWFlat.search / IndexFlat.search)"}
     del idx

@@ -234,6 +234,7 @@ class ShardedFlatIndex:
         # a list here makes every search append a (start, end) pair of timing events recorded on the lane's
         # stream around its all-gather (bench.py reports their mean)
         self.collective_events = None
+        self.step_events = None  # a list here makes submit() record a timing event behind every search
         self.unchecked = []  # searches of search_dev(check=False) whose status rows nobody has read yet
 
     @property
@@ -307,6 +308,10 @@ class ShardedFlatIndex:
         with torch.cuda.stream(side):
             D, I, status, err = self._search_on_current_stream(q, k, index)
             done = side.record_event()
+            if self.step_events is not None:  # (bench.py: a timing event behind every search, for per-step durations)
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(side)
+                self.step_events.append(ev)
         return PendingSearch(D, I, done, status, err)
 
     def search_dev(self, q, k, check=True):
