@@ -58,7 +58,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define KNN355_DIFF_SCALAR_PAIRS 3 // ... the first three query pairs of a thread's half (all of them up to 12 queries), the others through the LDS
 #endif
 #ifndef KNN355_EPI_PRIO
-#define KNN355_EPI_PRIO 2 // issue priority of a wave behind its K loop (two workgroups per CU; 0: never raised, for the A/B)
+#define KNN355_EPI_PRIO 0 // issue priority of a wave behind its K loop (two workgroups per CU).  Measured with 2 against 0 on one box: CATH-sized
+                          // symmetric kernel 2.21-2.22 vs 2.25 ms, 10 M-row step 6.874 vs 6.886 ms, shard step 0.916 vs 0.914 ms -- nothing: off
 #endif
 #ifndef KNN355_STREAM_DMA_FIRST
 #define KNN355_STREAM_DMA_FIRST 1 // streaming launches issue a K step's staging instructions in front of its first MFMA (flat_scan_kernel)
@@ -1669,12 +1670,12 @@ __global__ __launch_bounds__(256, (TM * TN >= 16 ? 1 : 2)) void flat_scan_kernel
             __syncthreads();           // (the next tile's prologue stages into these buffers)
         }
         KNN_TRACE(1 + 2 * tile_idx);
-        // Two workgroups per CU: behind its K loop a wave's vector instructions compete with the MFMAs of the OTHER workgroup's
-        // wave on the same SIMD, and that wave -- usually the older one -- wins the arbitration: the epilogue got about one
-        // instruction in per MFMA of the neighbour (the sparse epilogue of a CATH-sized symmetric tile, ~1500 instructions:
-        // 40-70 us beside a 75 us K loop, per-workgroup stamps; alone on the SIMD the same code takes 3 us).  Priority outranks
-        // age: raised for the epilogue, lowered again in front of the next K loop.  A dozen vector instructions fit into every
-        // gap of the neighbour's 64-cycle MFMAs, so its K loop does not pay for them.
+        // Two workgroups per CU: behind its K loop a wave's instructions run beside the MFMAs of the OTHER workgroup's wave on
+        // the same SIMD.  Straight-line vector code gets through at its own rate (the sparse epilogue's pass 1: 1.6 us for 64
+        // scores, alone on the CU or not); anything that WAITS -- an LDS round trip, an atomic's return, a barrier -- takes three
+        // to five times what it takes with the CU to itself (per-workgroup stamps of a CATH-sized symmetric tile: epilogue 57 us
+        // with two workgroups per CU, 17.5 us with one).  Raising the wave's issue priority here (s_setprio, compile-time knob)
+        // changes nothing measurable.
         if constexpr (!BIGT && KNN355_EPI_PRIO > 0) __builtin_amdgcn_s_setprio(KNN355_EPI_PRIO);
         if (paired && tid == 0) *s_next = next_tile; // (read by everyone behind the barrier that ends the epilogue)
 
