@@ -302,7 +302,7 @@ int32_t knn_scan_times(knn_handle h, float *out_ms, int32_t max_n);
  * rows scanned by the sample pass (the main scan kernel skips them) */
 int knn_last_seed_info(knn_handle h, int32_t *seed_stride, int32_t *stat_rank, int64_t *stat_redo,
                        int64_t *sample_rows);
-/* force a scan configuration: query_tile in {0(auto),32,48,64,96,128} (48 and 96: the builds on 16-query MFMA blocks, one
+/* force a scan configuration: query_tile in {0(auto),32,48,64,96,128,256} (48 and 96: the builds on 16-query MFMA blocks, one
  * query tile per launch -- honoured when the batch fits the tile, ignored otherwise); nchunks 0=auto (a forced count also turns the paired
  * walk off); flags, all off by default:
  *      2  no shared pool of tiles in a paired (one-query-tile) launch
@@ -322,6 +322,10 @@ int knn_last_seed_info(knn_handle h, int32_t *seed_stride, int32_t *stat_rank, i
  *  16384  never search the remainder behind the full 128-query tiles as a piece of its own (large databases: 129 queries
  *         are one 128-query launch and one streaming launch instead of two 128-query passes)
  * 131072  plans without the 48- and 96-query tiles (33..48 queries then pay for a 64-query tile, 65..96 for 128 or two pieces)
+ * 262144  never the 256 x 256 tile (one workgroup per CU; the library's choice for synchronous searches of >= 2048 queries over
+ *         >= 65 536 rows with long chunks, always under the statistical seed)
+ * 524288  the 256 x 256 tile wherever a batch holds more than 128 queries and the index >= 1024 rows, and 256-row tiles in the
+ *         symmetric whole-index self-search (tests, A/B)
  * Only 32 changes what a search returns (the other formula's rounding); every other combination returns the same bits. */
 int knn_set_tuning(knn_handle h, int32_t query_tile, int32_t nchunks, int32_t flags);
 
