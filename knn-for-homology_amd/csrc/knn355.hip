@@ -4386,7 +4386,8 @@ static bool self_search_symmetric_eligible(const knn_index_s *h, int k, int *j_o
 // D_host / I_host / d2h given and the result large: the query tiles are served in SYM_GROUPS launches of consecutive tiles, each
 // followed by the final selection of ITS rows -- a row's candidates are complete once every query tile up to its own has been
 // served (tile (I, J), J >= I, scores rows I against J and J against I) -- and by their download on the copy stream d2h, which
-// then overlaps the launches of the later groups (Pfam-sized k = 1000: 2.4 GB of results, 0.15 s behind a 0.38 s search).
+// then overlaps the launches of the later groups (Pfam-sized k = 1000: 2.4 GB of results, 0.15 s behind a 0.38 s search;
+// CATH-sized k = 301: 52 MB, 1.3 ms on the wire behind a 2.5 ms search, in four groups).
 // Returns 2 then (the caller waits for d2h and checks the verification flag), 1 when the results are in D_dev / I_dev only.
 static int self_search_symmetric(knn_index_s *h, int k, float *D_dev, int64_t *I_dev, hipStream_t s, float *D_host = nullptr,
                                  int64_t *I_host = nullptr, hipStream_t d2h = nullptr)
@@ -4423,28 +4424,37 @@ static int self_search_symmetric(knn_index_s *h, int k, float *D_dev, int64_t *I
     //    round trip -- 35 us of idle GPU -- per search).
     const int64_t slots = (TS == 256 ? 1 : 2) * (int64_t)std::max(1, h->num_cus);
     constexpr int SYM_GROUPS = 8;
-    const bool stream_out = D_host && I_host && d2h && (size_t)n * k * 12 >= ((size_t)256 << 20) && T >= 16 * SYM_GROUPS;
-    const int groups = stream_out ? SYM_GROUPS : 1;
+    // (eight groups for gigabytes of result; four from 32 MB on -- CATH-sized, 113 query tiles, 52 MB: cath.search end to end
+    // 5.03 -> 4.43 ms with four, 4.62 with five, 4.94 with eight: every group is a launch with its own tail and selection)
+    const int want_groups = std::min(SYM_GROUPS, std::max(2, dev_knob("KNN355_SELF_GROUPS", (size_t)n * k * 12 >= ((size_t)256 << 20) && T >= 16 * SYM_GROUPS ? SYM_GROUPS : 4)));
+    const bool stream_out = D_host && I_host && d2h && (size_t)n * k * 12 >= ((size_t)dev_knob("KNN355_SELF_STREAM_MIN_MB", 32) << 20) && T >= 16 * want_groups;
+    const int groups = stream_out ? want_groups : 1;
     if (h->sym_tiles != T || h->sym_ts != TS || h->sym_groups != groups || !h->ws_sym.p) {
-        int best_tp = 16;
-        int64_t best_cost = INT64_MAX;
-        for (int tp = dev_knob("KNN355_SYM_MIN_TP", 1); tp <= 96; tp++) {
-            int64_t wgs = 0;
-            for (int I = 0; I < T; I++) wgs += (T - I + tp - 1) / tp;
-            const int64_t rounds = (wgs + slots - 1) / slots;
-            const int64_t cost = rounds * (2 * tp + 1);
-            if (cost < best_cost || (cost == best_cost && tp > best_tp)) { best_cost = cost; best_tp = tp; }
-        }
+        // (the run length of each group by itself: a group is a launch, and a short one -- the later groups of a CATH-sized
+        // index -- fills the slots only with short runs)
         std::vector<SymItem> items;
         h->sym_gstart.assign(1, 0);
+        int first_tp = 16;
         for (int g = 0; g < groups; g++) { // (query tiles [T g / groups, T (g + 1) / groups): equal shares of the RESULT; the first group is the longest)
+            const int I0 = (int)((int64_t)T * g / groups), I1 = (int)((int64_t)T * (g + 1) / groups);
+            int best_tp = 16;
+            int64_t best_cost = INT64_MAX;
+            for (int tp = dev_knob("KNN355_SYM_MIN_TP", 1); tp <= 96; tp++) {
+                int64_t wgs = 0;
+                for (int I = I0; I < I1; I++) wgs += (T - I + tp - 1) / tp;
+                const int64_t rounds = (wgs + slots - 1) / slots;
+                const int64_t cost = rounds * (2 * tp + 1);
+                if (cost < best_cost || (cost == best_cost && tp > best_tp)) { best_cost = cost; best_tp = tp; }
+            }
+            if (g == 0) first_tp = best_tp;
             const size_t at = items.size();
-            for (int I = (int)((int64_t)T * g / groups); I < (int)((int64_t)T * (g + 1) / groups); I++)
+            for (int I = I0; I < I1; I++)
                 for (int j0 = I; j0 < T; j0 += best_tp) items.push_back({I, j0, std::min(best_tp, T - j0)});
             // long runs first: the short tails of every query tile fill the last round
             std::stable_sort(items.begin() + at, items.end(), [](const SymItem &a, const SymItem &b) { return a.jcount > b.jcount; });
             h->sym_gstart.push_back((int64_t)items.size());
         }
+        const int best_tp = first_tp;
         h->sym_tiles = -1;
         if (h->ws_sym.ensure(items.size() * sizeof(SymItem), h->done, s)) return set_err(KNN_ERR_HIP, "search_self: out of device memory");
         HIP_TRY(hipMemcpyAsync(h->ws_sym.p, items.data(), items.size() * sizeof(SymItem), hipMemcpyHostToDevice, s));
@@ -4752,7 +4762,7 @@ extern "C" int knn_flat_search_self(knn_handle h, int64_t row0, int64_t nrows, i
         std::unique_lock<std::mutex> pipes(cp.mu, std::defer_lock);
         hipStream_t d2h = nullptr;
         static const bool stream_off = getenv("KNN355_SELF_STREAM") && atoi(getenv("KNN355_SELF_STREAM")) == 0; // (A/B: the result in one piece behind the search)
-        if (!stream_off && (size_t)nrows * k * 12 >= ((size_t)256 << 20) && pipes.try_lock()) {
+        if (!stream_off && (size_t)nrows * k * 12 >= ((size_t)dev_knob("KNN355_SELF_STREAM_MIN_MB", 32) << 20) && pipes.try_lock()) {
             if (!cp.h2d) {
                 HIP_TRY(hipStreamCreateWithFlags(&cp.h2d, hipStreamNonBlocking));
                 HIP_TRY(hipStreamCreateWithFlags(&cp.d2h, hipStreamNonBlocking));
