@@ -91,10 +91,9 @@ class HipShardBackend:
             # queue (the runtime multiplexes its streams over a few), and then the lanes run strictly one after
             # the other -- measured: no overlap at all, two lanes = one lane
             prio = [int(v) for v in os.environ.get("KNN355_LANE_PRIORITIES", "0,-1").split(",")]
-            self._lanes = [(self.index, torch.cuda.Stream(self.device, priority=prio[0])),
-                           (self.index.view(), torch.cuda.Stream(self.device, priority=prio[1]))]
-        lane = self._lanes[self._turn]
-        self._turn ^= 1
+            self._lanes = [(self.index if i == 0 else self.index.view(), torch.cuda.Stream(self.device, priority=pr)) for i, pr in enumerate(prio)]
+        lane = self._lanes[self._turn % len(self._lanes)]
+        self._turn = (self._turn + 1) % len(self._lanes)
         return lane
 
     def reserve(self, n):
