@@ -219,6 +219,75 @@ __device__ __forceinline__ void wg_bitonic_sort(uint64_t *sb, int P, int tid, in
     }
 }
 
+// One wave, P = 64 E keys (E = 1, 2, 4, 8, 16): the same sort in registers.  Lane l holds elements l E .. l E + E - 1, so a
+// compare-exchange at distance j < E stays inside the lane (register indices and, for k2 <= E, directions known at compile
+// time) and one at distance j >= E meets lane l ^ (j / E) in the same register: two cross-lane moves per key instead of two
+// LDS reads, two LDS writes and a barrier per pair.  (The LDS sort of 512 keys costs a wave 720 eight-byte LDS operations;
+// with 56 one-wave selections per CU -- a CATH-sized all-vs-all -- that was 67 us of a 219 us kernel on the LDS pipe alone.)
+// value of lane (l ^ M) without the LDS crossbar where the vector pipe can do it: DPP inside a row of 16 lanes (quad
+// permutations for 1 and 2; 4 = "mirror the half row" (l ^ 7) then "reverse the quad" (l ^ 3); 8 = rotate the row by 8),
+// v_permlane16_swap / v_permlane32_swap (gfx950) across rows and wave halves
+template <int M>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v, int lane)
+{
+    if constexpr (M == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
+    else if constexpr (M == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);
+    else if constexpr (M == 4) return (uint32_t)__builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true), 0x1B, 0xF, 0xF, true);
+    else if constexpr (M == 8) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, true);
+    else if constexpr (M == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); // r[0]: odd rows <- the even rows below them; r[1]: even rows <- the odd rows above
+        return (lane & 16) ? r[0] : r[1];
+    } else {
+        static_assert(M == 32, "lane distance");
+        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        return (lane & 32) ? r[0] : r[1];
+    }
+}
+
+// one stage of the network: compare-exchange at distance J inside runs of K2 (element index = lane E + register)
+template <int E, int K2, int J>
+__device__ __forceinline__ void bitonic_stage_regs(uint64_t (&v)[E], int lane)
+{
+    if constexpr (J >= E) {
+        // (K2 >= 2 J >= 2 E here: the direction depends on the lane only; the last merge, K2 = 64 E, ascends everywhere)
+        const bool up = K2 >= 64 * E || (lane & (K2 / E)) == 0;
+        const bool keep_min = ((lane & (J / E)) == 0) == up;
+#pragma unroll
+        for (int r = 0; r < E; r++) {
+            const uint32_t ohi = lane_xor<J / E>((uint32_t)(v[r] >> 32), lane);
+            const uint32_t olo = lane_xor<J / E>((uint32_t)v[r], lane);
+            const uint64_t o = ((uint64_t)ohi << 32) | olo;
+            v[r] = ((o < v[r]) == keep_min) ? o : v[r];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < E; r++) {
+            if ((r & J) == 0) {
+                const uint64_t a = v[r], b = v[r | J];
+                bool up; // bit K2 of the element index is a bit of the register index when K2 < E, of the lane otherwise
+                if (K2 < E) up = (r & K2) == 0;
+                else up = K2 >= 64 * E || (lane & (K2 / E)) == 0;
+                const bool sw = (a > b) == up;
+                v[r] = sw ? b : a;
+                v[r | J] = sw ? a : b;
+            }
+        }
+    }
+    if constexpr (J > 1) bitonic_stage_regs<E, K2, J / 2>(v, lane);
+    else if constexpr (K2 < 64 * E) bitonic_stage_regs<E, 2 * K2, K2>(v, lane);
+}
+
+template <int E>
+__device__ __forceinline__ void wave_bitonic_sort_regs(uint64_t *sb, int lane)
+{
+    uint64_t v[E];
+#pragma unroll
+    for (int r = 0; r < E; r++) v[r] = sb[lane * E + r];
+    bitonic_stage_regs<E, 2, 1>(v, lane);
+#pragma unroll
+    for (int r = 0; r < E; r++) sb[lane * E + r] = v[r];
+}
+
 __device__ __forceinline__ int next_pow2_dev(int n)
 {
     int p = 64;
@@ -2805,7 +2874,18 @@ __global__ __launch_bounds__(NT) void select_topk_kernel(SelectParams p)
         pack(T, pos, sb, P);
         for (int i = cnt + tid; i < P; i += NT) sb[i] = KEY_PAD;
         __syncthreads();
-        wg_bitonic_sort(sb, P, tid, NT);
+        if (NT == 64 && P <= 1024) { // (one wave per query: the sort stays in registers)
+            switch (P) {
+            case 64: wave_bitonic_sort_regs<1>(sb, lane); break;
+            case 128: wave_bitonic_sort_regs<2>(sb, lane); break;
+            case 256: wave_bitonic_sort_regs<4>(sb, lane); break;
+            case 512: wave_bitonic_sort_regs<8>(sb, lane); break;
+            default: wave_bitonic_sort_regs<16>(sb, lane); break;
+            }
+            __syncthreads();
+        } else {
+            wg_bitonic_sort(sb, P, tid, NT);
+        }
         cnt = min(cnt, P);
         const int have = min(cnt, k); // real keys among the first k
         for (int i = tid; i < max(k, p.out_fill); i += NT) {

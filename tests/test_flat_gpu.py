@@ -144,6 +144,7 @@ def test_random_vs_oracle(gpu_faiss, oracle, nq, nb, d, k, qt, nch, metric):
     idx.set_tuning(qt, nch, 0)
     idx.add(xb)
     D, I = idx.search(xq, k)
+    assert idx.last_seed()["stat_rank"] > 0, idx.last_seed()
     Do, Io = oracle.flat_search(xb, xq, k, metric)
     _assert_same(D, I, Do, Io)
 
@@ -1167,3 +1168,23 @@ def test_read_rate_aid_reads_the_index_rows(gpu_faiss):
     empty = gpu_faiss.IndexFlat(100, 0)
     _lib.check(_lib.lib().knn_flat_read_rate(empty._h, 2, ctypes.byref(ms), ctypes.byref(nbytes)))
     assert nbytes.value == 0 and ms.value == 0.0
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("k", [1, 40, 64, 100, 129, 301, 420, 600, 819, 820])
+def test_one_wave_final_selection_sorts_in_registers(gpu_faiss, oracle, k, metric):
+    """The batch regime's final selection (one wave per query, select_topk_kernel<R, 64>) sorts its k..1.25 k survivors in
+    registers (wave_bitonic_sort_regs<E>: 64 E keys, E = 1 .. 16) and falls back to the LDS sort beyond 1024: every E, the
+    boundary (k = 819 -> 1023 survivors at most, 820 -> 1025), ties (duplicated rows) -- oracle bits."""
+    rng = np.random.default_rng(1000 + k)
+    nb, nq, d = 16384, 640, 32  # (>= 512 queries, statistically seeded: ~1.3 j N / S + 1.25 k <= 2048 candidates per query up to k ~ 650)
+    xb = rng.standard_normal((nb, d), dtype=np.float32)
+    xb[3000:3100] = xb[:100]
+    xq = rng.standard_normal((nq, d), dtype=np.float32)
+    xq[:5] = xb[:5]
+    idx = gpu_faiss.IndexFlat(d, metric)
+    idx.add(xb)
+    D, I = idx.search(xq, k)
+    assert k < 40 or idx.last_seed()["stat_rank"] > 0, idx.last_seed()  # (no estimate for a single neighbour)
+    Do, Io = oracle.flat_search(xb, xq, k, metric)
+    _assert_same(D, I, Do, Io)
