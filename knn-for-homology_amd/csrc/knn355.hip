@@ -3184,6 +3184,7 @@ struct knn_index_s {
     DevBuf ws_qdiff;              // difference builds: the queries interleaved by pairs
     DevBuf ws_defer;              // tile-minimum seed: the parked first-tile scores of every workgroup
     DevBuf ws_turn;               // batch launches: one word per CU (the resident workgroups take turns in their K loops)
+    void *turn_zeroed = nullptr;  // the ws_turn allocation that has been cleared (every holder gives its word back: a launch leaves them all zero)
     int64_t sym_searches = 0;     // self-searches served by the symmetric path
     static const int MAX_LEVELS = 8;
     LevelBufs ws_level[MAX_LEVELS]; // per seed-recursion level
@@ -4136,7 +4137,10 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     }
     if (pl.nqtiles > 1 && !h->approx16 && pl.tiles_base >= 2 && pl.qt != 256 && !(h->flags & 256)) { // (turn taking: batch launches with real chunks, two workgroups per CU)
         if (h->ws_turn.ensure(2048 * 4, h->done, s)) return set_err(KNN_ERR_HIP, "search: out of device memory");
-        HIP_TRY(hipMemsetAsync(h->ws_turn.p, 0, 2048 * 4, s));
+        if (h->turn_zeroed != h->ws_turn.p) { // (once per allocation: a fill in front of every launch was 10 us of idle GPU per CATH-sized search)
+            HIP_TRY(hipMemsetAsync(h->ws_turn.p, 0, 2048 * 4, s));
+            h->turn_zeroed = h->ws_turn.p;
+        }
         p.cu_turn = (uint32_t *)h->ws_turn.p;
     }
     // the pool: about a tenth of every pair's tiles (none with flags & 2)
@@ -4568,7 +4572,10 @@ static int self_search_symmetric(knn_index_s *h, int k, float *D_dev, int64_t *I
     p.fail = (int *)h->ws_flag.p;
     if (!(h->flags & 256) && TS == 128) {
         if (h->ws_turn.ensure(2048 * 4)) return set_err(KNN_ERR_HIP, "search_self: out of device memory");
-        HIP_TRY(hipMemsetAsync(h->ws_turn.p, 0, 2048 * 4, s));
+        if (h->turn_zeroed != h->ws_turn.p) {
+            HIP_TRY(hipMemsetAsync(h->ws_turn.p, 0, 2048 * 4, s));
+            h->turn_zeroed = h->ws_turn.p;
+        }
         p.cu_turn = (uint32_t *)h->ws_turn.p;
     }
     // + thresholds, per-half counts and bases of the tile's rows (+ 8 KB of slots for the 128-row tile's sparse epilogue, see lds_main in the kernel)
