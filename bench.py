@@ -603,8 +603,8 @@ def kernel_source_sha256():
 
 def shard_sweep_reference(rows, in_flight):
     """the committed one-GPU step time of a shard of `rows` rows (tools/shard_sweep.py), newest profile first"""
-    for name in ("r04_shard_sweep.json", "r03_shard_sweep.json"):
-        f = ROOT / "profiles" / name
+    for f in sorted((ROOT / "profiles").glob("r[0-9][0-9]_shard_sweep.json"), reverse=True):
+        name = f.name
         try:
             for rec in json.loads(f.read_text())["rows"]:
                 if rec.get("rows") == rows and rec.get("flags", 0) == 0:

@@ -29,7 +29,7 @@ def short(name):
     # the metric is part of the name (the bench's main config is inner product, its batch config L2)
     if "flat_scan_kernel<" in name:
         targs = name[name.index("flat_scan_kernel<") + len("flat_scan_kernel<"):].split(">")[0].split(", ")
-        tile = {"4, 1, 2, 1": "flat_scan_q32_d256", "2, 2, 2, 1": "flat_scan_q64_d128", "2, 2, 2, 2": "flat_scan_q128_d128"}[", ".join(targs[:4])]
+        tile = {"4, 1, 2, 1": "flat_scan_q32_d256", "2, 2, 2, 1": "flat_scan_q64_d128", "2, 2, 2, 2": "flat_scan_q128_d128", "2, 2, 4, 4": "flat_scan_q256_d256"}[", ".join(targs[:4])]
         if len(targs) > 9 and targs[9] != "0":  # builds on 16-query blocks: 4 x 1 waves -> 48 queries, 2 x 2 waves -> 96
             tile = "flat_scan_q48_d256" if targs[0] == "4" else "flat_scan_q96_d128"
         if len(targs) > 8 and targs[8] != "0":  # difference builds (squared L2, fewer than 20 queries)
