@@ -3,8 +3,8 @@ Pfam full-sequence embeddings, k = 1000).
 
 Which index for which size (one MI355X, d = 1024): at this script's size -- 200 k rows -- the EXACT ``flat``
 mode is also the fastest: 0.42 s for the all-vs-all k = 1000 search against 0.88 s for ``hnsw`` (M = 42, efSearch 256:
-recall@300 0.95, recall@1000 0.81 -- the sequential CPU oracle of the same graph parameters reaches 0.88 / 0.74 on these
-rows, tests/golden/hnsw_refshape_200k.npz) and 0.21 s for ``lsh``.  HNSW pays from about 2 M rows on (10 M rows, k = 100:
+recall@300 0.95, recall@1000 0.81 -- a sequential CPU construction with the same graph parameters reaches 0.88 / 0.74 on
+these rows, tests/golden/hnsw_refshape_200k.npz) and 0.21 s for ``lsh``.  HNSW pays from about 2 M rows on (10 M rows, k = 100:
 440-590 k queries/s at recall 0.984-0.988 against 6.6 k for the exact scan); a graph search of fewer than ~1000 queries is
 latency-bound (1.2 ms for one query against 0.30 ms for the exact scan of 200 k rows).
 
