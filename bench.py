@@ -730,12 +730,17 @@ def nq_sweep(index, dev, L, _lib, d, k, nb):
         q = torch.from_numpy(qh).to(dev)
         _lib.check(L.knn_normalize_l2_dev(q.data_ptr(), nq, d, None))
         reps = 2 if nq >= 10_000 else (3 if nq >= 1024 else 8)
-        index.search_dev(q, k)
+        # One rank, a batch of many query tiles: the synchronous entry (what IndexFlat.search runs on device buffers) -- it may
+        # take the statistical seed, whose verification flag it reads before returning, and with it the 256 x 256 tile; the
+        # lanes of the sharded index are asynchronous and never do.  Several ranks: the sharded path, as in the timed steps.
+        sync_entry = index.world == 1 and nq >= 1024
+        run = (lambda: index.backend.search(q, k)) if sync_entry else (lambda: index.search_dev(q, k))
+        run()
         torch.cuda.synchronize()
         times, scans = [], []
         for _ in range(reps):
             t0 = time.perf_counter()
-            index.search_dev(q, k)
+            run()
             torch.cuda.synchronize()
             times.append(time.perf_counter() - t0)
             scans.append(index.local.last_scan()["ms"])
@@ -746,17 +751,26 @@ def nq_sweep(index, dev, L, _lib, d, k, nb):
         by = passes * rows * d * 4 + nq * d * 4 + nq * k * 12
         fl = 2.0 * nq * rows * d
         if nq > 1024:
-            # several launches (full 128-query tiles + the remainder on a narrower build): last_scan() describes the last one
-            # only -- the whole search's time is the denominator
-            passes = (nq + 127) // 128
-            rec = {"nq": nq, "queries_per_s": nq / t, "ms": 1e3 * t, "kernel": "flat_scan_q128_d128 (+ the remainder's launch)", "kernel_ms": None,
+            # several launches (full query tiles + the remainder on a narrower build): last_scan() describes the last one only --
+            # the whole search's time is the denominator, and the tile of the full launches is read from a search of the
+            # queries in front of the remainder (not timed)
+            if sync_entry and nq - nq % 256 > 0:
+                index.backend.search(q[:nq - nq % 256].contiguous(), k)
+                torch.cuda.synchronize()
+                info = index.local.last_scan()
+            passes = (nq + info["query_tile"] - 1) // info["query_tile"] if info["query_tile"] >= 128 else (nq + 127) // 128
+            rec = {"nq": nq, "queries_per_s": nq / t, "ms": 1e3 * t, "kernel": info["kernel"] + " (+ the remainder's launch)", "kernel_ms": None,
                    "db_passes": passes, "hbm_frac": (passes * rows * d * 4 + nq * d * 4 + nq * k * 12) / t / 1e9 / HBM_PEAK_GBS,
                    "mfma_frac": fl / t / 1e12 / FP32_MFMA_PEAK_TF, "bound": "mfma", "basis": "whole search (all launches, selections included)"}
+            if sync_entry:
+                rec["entry"] = "synchronous (IndexFlat.search on device buffers): statistical seed allowed"
             res.append(rec)
             continue
         rec = {"nq": nq, "queries_per_s": nq / t, "ms": 1e3 * t, "kernel": info["kernel"], "kernel_ms": sm, "db_passes": passes,
                "hbm_frac": by / (sm * 1e-3) / 1e9 / HBM_PEAK_GBS, "mfma_frac": fl / (sm * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF}
         rec["bound"] = "hbm" if passes == 1 else "mfma"
+        if sync_entry:
+            rec["entry"] = "synchronous (IndexFlat.search on device buffers): statistical seed allowed"
         res.append(rec)
     return res
 
