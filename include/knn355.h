@@ -102,7 +102,9 @@ int knn_flat_search_self(knn_handle h, int64_t row0, int64_t nrows, int64_t k, f
                          int64_t *I_host);
 /* A self-search of the WHOLE index (row0 = 0, nrows = ntotal) multiplies only the score tiles on and
  * above the diagonal: dot(x, y) = dot(y, x) bit for bit, so the tile of (query tile I, database tile J)
- * also serves (query tile J, database tile I) -- half the matrix work, the same bits.
+ * also serves (query tile J, database tile I) -- half the matrix work, the same bits.  Results of 32 MB
+ * or more reach D_host / I_host in groups of query tiles (four; eight from 256 MB on) while the later
+ * groups are still being multiplied: the arrays are complete when the call returns, not before.
  * knn_flat_search_self_dev: the same search with the results left on the device (synchronous). */
 int knn_flat_search_self_dev(knn_handle h, int64_t k, float *D_dev, int64_t *I_dev);
 int knn_flat_normalize_rows(knn_handle h);
