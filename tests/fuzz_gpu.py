@@ -32,8 +32,8 @@ def run(ncases=200, seed=1, budget_s=None):
             nq = max(1, int(3e10 / (nb * d)))
         k = int(rng.choice([1, 2, 10, 11, 64, 100, 101, 301, 512, 1000, 1537, 2048]))
         metric = int(rng.integers(0, 2))
-        flags = int(rng.choice([0, 0, 0, 8, 16, 128, 128]))
-        qt = int(rng.choice([0, 0, 0, 0, 32, 48, 64, 96, 128]))
+        flags = int(rng.choice([0, 0, 0, 8, 16, 128, 128, 524288, 524288 | 128, 262144]))  # (524288: the 256 x 256 tile wherever a batch holds > 128 queries)
+        qt = int(rng.choice([0, 0, 0, 0, 32, 48, 64, 96, 128, 256]))
         nch = int(rng.choice([0, 0, 0, 1, 3, 17]))
         kind = int(rng.integers(0, 6))
         if kind == 0:
