@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer fuzz: random shapes / metrics / k / tuning flags of the flat search against the CPU
 oracle, bit for bit.  Data mixes: gaussian, few distinct values (massive ties), duplicated rows,
-sorted columns, tiny norms, constant rows.  usage: fuzz_gpu.py [ncases] [seed]"""
+sorted columns, tiny norms, constant rows.  usage: fuzz_gpu.py [ncases] [seed] [budget seconds]"""
 import sys
 import time
 from pathlib import Path
@@ -73,4 +73,5 @@ def run(ncases=200, seed=1, budget_s=None):
 if __name__ == "__main__":
     _n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     _s = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    sys.exit(1 if run(_n, _s)[0] else 0)
+    _b = float(sys.argv[3]) if len(sys.argv) > 3 else None  # stop starting new cases after that many seconds
+    sys.exit(1 if run(_n, _s, _b)[0] else 0)
