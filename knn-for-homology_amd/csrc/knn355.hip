@@ -3793,7 +3793,9 @@ static bool big_tile_pays(const knn_index_s *h, int64_t nb, int64_t nq)
     if (nb < 65536) return false; // (never a seed sample's own scan)
     const int64_t cus = std::max(1, h->num_cus);
     const int64_t work = ((nq + 255) / 256) * ((nb + 255) / 256); // 256 x 256 tiles of the search
-    return nq >= dev_knob("KNN355_BIG_MIN_NQ", 2048) && work >= (int64_t)dev_knob("KNN355_BIG_MIN_TILES_PER_CU", 32) * cus;
+    // (from two query tiles on: 10 M rows x 512 / 768 / 1024 / 1536 queries 79.1 / 117.6 / 152.4 / 234.4 ms against 89.4 / 130.8 /
+    // 172.0 / 248.8 on the 128 x 128 tile, one box; until late in round 5 the bound was 2048)
+    return nq >= dev_knob("KNN355_BIG_MIN_NQ", 512) && work >= (int64_t)dev_knob("KNN355_BIG_MIN_TILES_PER_CU", 32) * cus;
 }
 
 static void make_plan(const knn_index_s *h, int64_t nb, int64_t nq, int k, bool seeded, ScanPlan &pl, bool allow_pairs = false, bool allow_big = true)
@@ -3958,6 +3960,12 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
     bool seed = nb >= 512 * (int64_t)k && std::max<int64_t>(2 * pl.chunk_rows, 64 * (int64_t)k) <= nb / 32;
     if (h->flags & 16) seed = nb >= 8192 && nb >= 32 * (int64_t)k;
     if (h->flags & (8 | 128)) seed = false;
+    // (the 256 x 256 tile under a caller that can check the verification flag: the statistical estimate from every 256th row
+    // instead of an exact search of every 32nd -- 10 M rows x 512 / 768 / 1536 queries 0.854 / 0.869 / 0.858 of the MFMA peak with
+    // the exact seed where 1024 / 2048 queries, which the rule above leaves to the estimate, reach 0.887; the exact seed stays
+    // the fallback when no rank qualifies)
+    const bool exact_ok = seed;
+    if (seed && pl.qt == 256 && allow_stat && level == 0 && row_mul == 1 && !(h->flags & (8 | 16 | 512))) seed = false;
     int sstride = seed ? seed_stride(nb, k, pl.chunk_rows) : 0;
     int seed_j = k, seed_stat = 0, svshift = vshift;
     double expect_n = 0; // typical candidates per query at the final selection (0: unknown, assume the capacity)
@@ -3998,6 +4006,10 @@ static int search_view(knn_index_s *h, const float *q_dev, const float *xn, int6
                 svshift = 0;
                 expect_n = 1.3 * seeded + 1.25 * k; // (the bound's rank is in [j, 1.25 j]) + the sample's own rows
             }
+        }
+        if (!seed_stat && exact_ok) { // (no estimate after all: the exact seed the rule had chosen)
+            seed = true;
+            sstride = seed_stride(nb, k, pl.chunk_rows);
         }
     }
     // Tile-minimum seed (see flat_scan_kernel): where the exact seed would run a sample pass first, a launch with enough
@@ -4276,13 +4288,24 @@ static int search_keys_impl(knn_index_s *h, const float *q_dev, int64_t nq, int 
     const bool split_small = !split && h->ntotal >= (1 << 15) && nq > 64 && nq <= 128 && !h->force_qt && !h->force_chunks && !h->approx16 &&
                              !(h->flags & (8 | 16 | 128 | 2048 | 16384)) && (k <= 200 || !allow_stat || (h->flags & 512));
     for (int64_t b = 0; b < nblocks; b++) {
-        const int64_t q0 = b * QB, m = nblocks == 1 ? nq : std::min(QB, nq - q0);
+        int64_t q0 = b * QB, m = nblocks == 1 ? nq : std::min(QB, nq - q0);
         if (split_small) {
             pieces.push_back({q0, 64});
             pieces.push_back({q0 + 64, m - 64});
             continue;
         }
-        const int64_t full = m / 128 * 128, r = m - full;
+        int64_t full = m / 128 * 128;
+        const int64_t r = m - full;
+        // A batch the 256 x 256 tile serves (big_tile_pays; synchronous callers: it needs the statistical seed) whose full tiles
+        // end in half a 256-query tile: that half goes with the remainder, on the 128 x 128 tile -- 10 M rows x 640 queries:
+        // 512 on the wide tile + 128 on the narrow one, not three wide query tiles of which one is half empty.
+        const bool may_big = (allow_stat && !(h->flags & (8 | 16 | 512))) || (h->flags & 524288);
+        if (split && may_big && !h->force_chunks && full % 256 == 128 && full >= 384 && big_tile_pays(h, h->ntotal, full - 128)) {
+            pieces.push_back({q0, full - 128});
+            q0 += full - 128;
+            m -= full - 128;
+            full = 128;
+        }
         // (round 4: 33..48 and 65..96 queries have builds of their own width -- 16-query blocks, make_plan -- so a remainder of
         // up to 96 queries is one piece: 10 M rows x 80 queries: 18.7 ms as 64 + 16, ~16 as one 96-query pass)
         const bool q96 = !h->approx16 && !(h->flags & 131072);

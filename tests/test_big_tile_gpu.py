@@ -137,3 +137,22 @@ def test_symmetric_big_tiles_repair_a_failed_estimate(gpu_faiss, oracle):
     assert idx.last_seed()["stat_redo"] > before
     sample = np.concatenate([near[:20], rng.choice(n, 20, replace=False)])
     _assert_same(D[sample], I[sample], *oracle.flat_search(x, x[sample], k, 0))
+
+
+def test_half_a_wide_query_tile_goes_with_the_remainder(gpu_faiss, oracle):
+    """A database that is streamed from HBM (>= 2^18 rows: batches are cut into pieces) and a batch the 256 x 256 tile serves whose
+    full 128-query tiles end in half a wide tile: 640 queries = 512 on the wide tile + 128 on the 128 x 128 tile, 936 = 768 +
+    128 + a 40-query remainder -- not a third / fourth wide query tile that is half empty.  Same bits as the oracle."""
+    rng = np.random.default_rng(91)
+    nb, d, k = 300_000, 32, 10
+    xb = rng.standard_normal((nb, d), dtype=np.float32)
+    xb[200_000:200_050] = xb[:50]
+    idx = gpu_faiss.IndexFlat(d, 0)
+    idx.add(xb)
+    idx.set_tuning(0, 0, BIG)
+    for nq, last_tile in ((512, 256), (640, 128), (936, 48), (1024, 256)):
+        xq = rng.standard_normal((nq, d), dtype=np.float32)
+        xq[:3] = xb[:3]
+        D, I = idx.search(xq, k)
+        assert idx.last_scan()["query_tile"] == last_tile, (nq, idx.last_scan())
+        _assert_same(D, I, *oracle.flat_search(xb, xq, k, 0))
