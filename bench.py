@@ -92,8 +92,46 @@ BENCH_TIMEOUT_S = float(os.environ.get("KNN355_BENCH_TIMEOUT_S", "480"))
 _T0 = time.time()
 
 
+_PARTIAL = {"out": None, "stage": "start", "fd": None}
+
+
+def deadline_watch(deadline_s):
+    """One-process runs (N = 1): nothing bounds an in-process stall -- a sick box, a host leg that never returns.  After
+    deadline_s/2 the Python stacks go to stderr once (which leg, which library call); at deadline_s the JSON line goes out
+    with what has been measured so far and an "incomplete" key naming the stage, provided the headline is in it (exit 0);
+    otherwise exit 124.  The N-rank launch has its own bounds (self_launch)."""
+    import faulthandler
+    import threading
+    faulthandler.dump_traceback_later(max(60.0, deadline_s / 2), repeat=False, file=sys.stderr)
+
+    def fire():
+        time.sleep(deadline_s)
+        print(f"bench.py: not finished after {deadline_s:.0f} s (KNN355_BENCH_DEADLINE_S), stage: {_PARTIAL['stage']}", file=sys.stderr, flush=True)
+        try:
+            faulthandler.dump_traceback(file=sys.stderr)
+        except Exception:
+            pass
+        out, fd = _PARTIAL["out"], _PARTIAL["fd"]
+        if out is not None and fd is not None:
+            for _ in range(5):
+                try:
+                    rec = dict(out)
+                    rec["incomplete"] = {"stage": _PARTIAL["stage"], "deadline_s": deadline_s,
+                                         "note": "the legs behind this stage are missing: the run was cut at its deadline"}
+                    os.write(fd, (json.dumps(rec) + "\n").encode())
+                    os._exit(0)
+                except RuntimeError:  # (the main thread added a key meanwhile)
+                    time.sleep(0.05)
+        os._exit(124)
+
+    threading.Thread(target=fire, daemon=True).start()
+
+
 def progress(stage):
-    """Rank side: append '<seconds since start> <stage>' to this rank's marker file (no-op outside a self-launched run)."""
+    """Rank side: '<seconds since start> <stage>' on rank 0's stderr and, in a self-launched run, in this rank's marker file."""
+    _PARTIAL["stage"] = stage
+    if os.environ.get("RANK", "0") == "0":  # (one line per stage on rank 0's stderr: a run that stalls says where)
+        print(f"[bench {time.time() - _T0:7.1f}s] {stage}", file=sys.stderr, flush=True)
     pdir = os.environ.get("KNN355_PROGRESS_DIR")
     if not pdir:
         return
@@ -264,6 +302,9 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    if "WORLD_SIZE" not in os.environ:
+        _PARTIAL["fd"] = real_stdout
+        deadline_watch(float(os.environ.get("KNN355_BENCH_DEADLINE_S", "900")))
     try:
         line = run(args)
     finally:
@@ -432,16 +473,25 @@ def run(args):
     alg_bytes = passes * rows_kernel * d * 4 + nq * d * 4 + nq * k * 12
     avg_scan_ms = float(np.mean(scan_ms)) if scan_ms else None
 
-    # ---- the other multi-GPU split: Pfam-sized all-vs-all, rows replicated, queries split ----------
-    allvsall = None
-    if not args.no_batch:
-        allvsall = query_sharded_all_vs_all(dev, L, _lib, faiss, rank, world, dist if use_pg else None)
 
-    hnsw_rep = None
-    if world > 1 and not args.no_extras:
-        hnsw_rep = hnsw_replicas(dev, L, _lib, faiss, rank, world, dist)
+    # the legs every rank takes part in (rank 0 runs them once its headline is assembled: a run cut at its deadline keeps it)
+    def all_rank_legs():
+        res = {}
+        # the other multi-GPU split: Pfam-sized all-vs-all, rows replicated, queries split
+        if not args.no_batch:
+            progress("all_vs_all_query_sharded")
+            a = query_sharded_all_vs_all(dev, L, _lib, faiss, rank, world, dist if use_pg else None)
+            if a is not None:
+                res["all_vs_all_query_sharded"] = a
+        if world > 1 and not args.no_extras:
+            progress("hnsw_replicas")
+            hr = hnsw_replicas(dev, L, _lib, faiss, rank, world, dist)
+            if hr is not None:
+                res["hnsw_replicas"] = hr
+        return res
 
     if rank != 0:
+        all_rank_legs()
         dist.destroy_process_group()
         return None
 
@@ -535,15 +585,18 @@ def run(args):
                     "GBs": read_gbs, "ms": ms_read.value, "bytes": nbytes.value, "frac_of_it": achieved / read_gbs,
                     "what": "knn_flat_read_rate: grid-stride 16-byte loads over the index's own rows, best of 15 launches"}
 
-    if allvsall is not None:
-        out["all_vs_all_query_sharded"] = allvsall
-    if hnsw_rep is not None:
-        out["hnsw_replicas"] = hnsw_rep
+    _PARTIAL["out"] = out  # (from here on a run cut at its deadline still prints the headline and the legs that finished)
+    progress("headline done; extras")
+    out.update(all_rank_legs())
     if world == 1 and not args.no_extras:
+        progress("shard_unit")
         out["shard_unit"] = shard_unit_step(dev, L, _lib, faiss, d, k, q)
+        progress("sweep")
         out["sweep"] = nq_sweep(index, dev, L, _lib, d, k, nb_local)
+        progress("host_buffers")
         out["host_buffers"] = host_buffer_step(index, q.cpu().numpy(), k)
     if world == 1 and not args.no_cpu and cpu_rows is not None:
+        progress("cpu_baseline")
         out["cpu_baseline"] = cpu_baseline(cpu_rows, q.cpu().numpy(), k, args.nb_total)
         cpu_rows.close()
     if world == 1 and not (args.no_batch and args.no_extras):
@@ -551,9 +604,12 @@ def run(args):
         torch.cuda.empty_cache()
         L.knn_trim()
         if not args.no_batch:
+            progress("batch")
             out["batch"] = batch_config(dev, L, _lib, faiss)
         if not args.no_extras:
+            progress("hnsw")
             out["hnsw"] = hnsw_config(dev, L, _lib, faiss)
+        progress("done")
         rd = real_data()
         if rd:
             out["real_data"] = rd
