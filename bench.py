@@ -304,7 +304,7 @@ def main():
     os.dup2(2, 1)
     if "WORLD_SIZE" not in os.environ:
         _PARTIAL["fd"] = real_stdout
-        deadline_watch(float(os.environ.get("KNN355_BENCH_DEADLINE_S", "900")))
+        deadline_watch(float(os.environ.get("KNN355_BENCH_DEADLINE_S", "600")))
     try:
         line = run(args)
     finally:
