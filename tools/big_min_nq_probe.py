@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""10 M x 1024 rows, one synchronous search of nq queries (k = 100): which tile the plan takes and what it costs.
+"""ROWS (default 10 M) x 1024 rows, one synchronous search of nq queries (k = 100): which tile the plan takes and what it costs.
 Developer build + KNN355_BIG_MIN_NQ=<n> moves the 256 x 256 tile's lower bound; FLAGS=<tuning flags> (524288: the 256 x 256
 tile wherever a batch holds more than 128 queries, 262144: never).  usage: [FLAGS=n] big_min_nq_probe.py nq [nq ...]"""
 import os, sys, time
@@ -14,9 +14,10 @@ idx = faiss.IndexFlat(d, 0)
 _lib.check(L.knn_flat_reserve(idx._h, nb))
 g = torch.Generator(device=dev); g.manual_seed(23)
 for i0 in range(0, nb, 500_000):
-    x = torch.randn((500_000, d), generator=g, device=dev)
-    _lib.check(L.knn_normalize_l2_dev(x.data_ptr(), 500_000, d, None))
-    _lib.check(L.knn_flat_add_dev(idx._h, x.data_ptr(), 500_000, None))
+    m = min(500_000, nb - i0)
+    x = torch.randn((m, d), generator=g, device=dev)
+    _lib.check(L.knn_normalize_l2_dev(x.data_ptr(), m, d, None))
+    _lib.check(L.knn_flat_add_dev(idx._h, x.data_ptr(), m, None))
     del x
 idx.set_tuning(0, 0, int(os.environ.get('FLAGS', '0')))
 for nq in [int(a) for a in sys.argv[1:]] or [1024]:
