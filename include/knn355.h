@@ -324,7 +324,7 @@ int knn_last_seed_info(knn_handle h, int32_t *seed_stride, int32_t *stat_rank, i
  *  16384  never search the remainder behind the full 128-query tiles as a piece of its own (large databases: 129 queries
  *         are one 128-query launch and one streaming launch instead of two 128-query passes)
  * 131072  plans without the 48- and 96-query tiles (33..48 queries then pay for a 64-query tile, 65..96 for 128 or two pieces)
- * 262144  never the 256 x 256 tile (one workgroup per CU; the library's choice for synchronous searches of >= 512 queries over
+ * 262144  never the 256 x 256 tile (one workgroup per CU; the library's choice for synchronous searches of >= 256 queries over
  *         >= 65 536 rows with long chunks, always under the statistical seed)
  * 524288  the 256 x 256 tile wherever a batch holds more than 128 queries and the index >= 1024 rows, and 256-row tiles in the
  *         symmetric whole-index self-search (tests, A/B)

@@ -3793,9 +3793,9 @@ static bool big_tile_pays(const knn_index_s *h, int64_t nb, int64_t nq)
     if (nb < 65536) return false; // (never a seed sample's own scan)
     const int64_t cus = std::max(1, h->num_cus);
     const int64_t work = ((nq + 255) / 256) * ((nb + 255) / 256); // 256 x 256 tiles of the search
-    // (from two query tiles on: 10 M rows x 512 / 768 / 1024 / 1536 queries 79.1 / 117.6 / 152.4 / 234.4 ms against 89.4 / 130.8 /
-    // 172.0 / 248.8 on the 128 x 128 tile, one box; until late in round 5 the bound was 2048)
-    return nq >= dev_knob("KNN355_BIG_MIN_NQ", 512) && work >= (int64_t)dev_knob("KNN355_BIG_MIN_TILES_PER_CU", 32) * cus;
+    // (from ONE wide query tile on: 10 M rows x 256 / 512 / 768 / 1024 / 1536 queries 38.1 / 79.1 / 117.6 / 152.4 / 234.4 ms against
+    // 41.4 / 89.4 / 130.8 / 172.0 / 248.8 on the 128 x 128 tile, one box; until late in round 5 the bound was 2048)
+    return nq >= dev_knob("KNN355_BIG_MIN_NQ", 256) && work >= (int64_t)dev_knob("KNN355_BIG_MIN_TILES_PER_CU", 32) * cus;
 }
 
 static void make_plan(const knn_index_s *h, int64_t nb, int64_t nq, int k, bool seeded, ScanPlan &pl, bool allow_pairs = false, bool allow_big = true)
