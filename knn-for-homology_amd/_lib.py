@@ -140,11 +140,18 @@ def device_count():
 # 4 GiB/s (3 GiB for a Pfam-sized k=1000 result: 0.7 s), a staged download into pageable memory loses about 0.08 s per
 # GB -- so a block larger than PINNED_FIRST_MAX is only allocated when its size class is asked for the SECOND time:
 # a script that searches once (pfam/proteins_search.py) never pays, a loop over files (cath/search.py) pays once.
+# A NEW block is only page-locked while fewer than PINNED_LIVE_PER_CLASS arrays of its size class are alive: a caller that
+# drops each result before the next search (or holds one while the next is computed) recycles two blocks for ever; a caller
+# that KEEPS every result -- cath/search.py:37-50 collects the hits of every file of a metric before it saves them -- would
+# otherwise page-lock a fresh block per search (52 MB of CATH-sized results: 13-23 ms, five times the search) and gets plain
+# arrays from its third live result on (a staged download: +1 ms).
 PINNED_MIN = 4 << 20
 PINNED_FIRST_MAX = 64 << 20
 PINNED_LIMIT = 4 << 30
+PINNED_LIVE_PER_CLASS = 2
 _pinned_free = {}    # size class -> [pointers]
 _pinned_seen = {}    # size class -> requests so far
+_pinned_live = {}    # size class -> arrays alive (handed out, not yet returned)
 _pinned_out = 0      # bytes handed out or cached
 
 
@@ -158,6 +165,7 @@ class _PinnedBlock:
     def __del__(self):
         try:
             _pinned_free.setdefault(self.cls, []).append(self.ptr)
+            _pinned_live[self.cls] = _pinned_live.get(self.cls, 1) - 1
         except Exception:  # interpreter shutdown
             pass
 
@@ -176,10 +184,12 @@ def result_array(shape, dtype):
     if ptr is None:
         seen = _pinned_seen.get(cls, 0)
         _pinned_seen[cls] = seen + 1
-        if _pinned_out + cls > PINNED_LIMIT or (cls > PINNED_FIRST_MAX and seen == 0):
+        if (_pinned_out + cls > PINNED_LIMIT or (cls > PINNED_FIRST_MAX and seen == 0)
+                or _pinned_live.get(cls, 0) >= PINNED_LIVE_PER_CLASS):
             return np.empty(shape, dt)
         ptr = lib().knn_host_alloc(cls)
         if not ptr:
             return np.empty(shape, dt)
         _pinned_out += cls
+    _pinned_live[cls] = _pinned_live.get(cls, 0) + 1
     return np.asarray(_PinnedBlock(ptr, nbytes, cls, tuple(int(v) for v in shape), dt.str))

@@ -1187,3 +1187,27 @@ def test_one_wave_final_selection_sorts_in_registers(gpu_faiss, oracle, k, metri
     assert k < 40 or idx.last_seed()["stat_rank"] > 0, idx.last_seed()  # (no estimate for a single neighbour)
     Do, Io = oracle.flat_search(xb, xq, k, metric)
     _assert_same(D, I, Do, Io)
+
+
+def test_results_that_are_kept_stop_taking_new_page_locked_blocks(gpu_faiss):
+    """cath/search.py:37-50 keeps the hits of every file of a metric until it saves them: from the third live result of a size
+    class on, a search returns plain arrays (a staged download) instead of page-locking one more block per search; dropping
+    the results brings the pooled blocks back."""
+    import gc
+    from knn_for_homology_amd import _lib
+    rng = np.random.default_rng(5)
+    xb = rng.standard_normal((2000, 16), dtype=np.float32)
+    xq = rng.standard_normal((5000, 16), dtype=np.float32)
+    idx = gpu_faiss.IndexFlat(16, 0)
+    idx.add(xb)
+    gc.collect()
+    cls = 1 << (5000 * 300 * 4 - 1).bit_length()
+    live0 = _lib._pinned_live.get(cls, 0)
+    kept = [idx.search(xq, 300) for _ in range(_lib.PINNED_LIVE_PER_CLASS - live0 + 2)]   # D: 6 MB (class 8 MB), I: 12 MB (class 16 MB)
+    pinned = [not D.flags.owndata for D, _ in kept]
+    assert pinned[0] and not pinned[-1] and not pinned[-2], pinned
+    assert all(np.array_equal(kept[0][1], I) for _, I in kept)   # the same result either way
+    del kept
+    gc.collect()
+    D, I = idx.search(xq, 300)
+    assert not D.flags.owndata and not I.flags.owndata
