@@ -430,3 +430,32 @@ def test_bench_parent_timeout_kills_the_run_it_started():
     assert p.returncode == 124 and took < 60, (p.returncode, took)
     assert "no result within KNN355_BENCH_TIMEOUT_S = 12 s (killed)" in p.stderr
     assert "rank(s) 1 stalled before init_process_group" in p.stderr
+
+
+def test_bench_one_rank_deadline_keeps_the_headline():
+    """A one-rank bench run has no parent to bound it: at KNN355_BENCH_DEADLINE_S the watchdog prints the JSON line with what
+    has been measured (the headline dict registered behind the timed steps) and an `incomplete` key naming the stage, exit 0;
+    with nothing registered yet it exits 124 and prints no line."""
+    import json
+    import subprocess
+    import textwrap
+    body = textwrap.dedent(f'''
+        import os, sys, time, importlib.util
+        sys.argv = ["bench.py"]
+        spec = importlib.util.spec_from_file_location("benchmod", r"{ROOT / 'bench.py'}")
+        m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+        real = os.dup(1); os.dup2(2, 1)
+        m._PARTIAL["fd"] = real
+        m.deadline_watch(1.0)
+        if os.environ.get("WITH_HEADLINE") == "1":
+            m._PARTIAL["out"] = {{"metric": "x", "value": 1.0, "roofline": {{"frac": 0.5}}}}
+        m.progress("sweep")
+        time.sleep(30)
+    ''')
+    p = subprocess.run([sys.executable, "-c", body], capture_output=True, text=True, timeout=60, env={**os.environ, "WITH_HEADLINE": "1"})
+    assert p.returncode == 0, p.stderr[-500:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["value"] == 1.0 and line["incomplete"]["stage"] == "sweep"
+    assert "[bench" in p.stderr and "sweep" in p.stderr
+    p = subprocess.run([sys.executable, "-c", body], capture_output=True, text=True, timeout=60, env={**os.environ, "WITH_HEADLINE": "0"})
+    assert p.returncode == 124 and not p.stdout.strip()
