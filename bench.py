@@ -323,6 +323,7 @@ def run(args):
     rehearse = os.environ.get("KNN355_REHEARSE_ONE_GPU", "0") == "1"
     if rehearse:
         local_rank = 0
+    progress("run: selecting the device")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -337,6 +338,7 @@ def run(args):
     from knn_for_homology_amd.sharded import ShardedFlatIndex, shard_bounds
     L = _lib.lib()
     _lib.check(L.knn_init(local_rank))
+    progress("library loaded, device initialised")
 
     d, k, nq = args.d, args.k, args.nq
     if args.scaling == "weak":
