@@ -234,3 +234,24 @@ def test_query_sharded_search_waits_for_the_kernels_that_produce_q(gpu_faiss, or
         torch.cuda.synchronize()
         assert np.array_equal(I.cpu().numpy(), Io)
         assert np.array_equal(D.cpu().numpy().view(np.uint32), Do.view(np.uint32))
+
+
+def test_one_rank_large_batch_takes_the_synchronous_entry(gpu_faiss, oracle):
+    """search_dev on ONE rank with more than 128 queries and a caller that waits (check=True): the synchronous entry -- it may
+    take the statistical seed (the lanes never do) -- and the bits of the lanes' result and of the oracle."""
+    import torch
+    from knn_for_homology_amd.sharded import ShardedFlatIndex
+    rng = np.random.default_rng(78)
+    xb = rng.standard_normal((20000, 64), dtype=np.float32)
+    xq = rng.standard_normal((300, 64), dtype=np.float32)
+    idx = ShardedFlatIndex(64, gpu_faiss.METRIC_INNER_PRODUCT)
+    idx.add(xb)
+    q = torch.from_numpy(xq).to(idx.backend.device)
+    D, I = idx.search_dev(q, 100)
+    torch.cuda.synchronize()
+    assert idx.local.last_seed()["stat_rank"] > 0, idx.local.last_seed()          # the statistical seed: the synchronous entry ran
+    Dl, Il = idx.submit(q, 100).result()                                           # the lanes
+    torch.cuda.synchronize()
+    Do, Io = oracle.flat_search(xb, xq, 100, 0)
+    for d_, i_ in ((D, I), (Dl, Il)):
+        assert np.array_equal(i_.cpu().numpy(), Io) and np.array_equal(d_.cpu().numpy().view(np.uint32), Do.view(np.uint32))
