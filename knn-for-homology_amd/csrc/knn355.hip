@@ -3793,9 +3793,11 @@ static bool big_tile_pays(const knn_index_s *h, int64_t nb, int64_t nq)
     if (nb < 65536) return false; // (never a seed sample's own scan)
     const int64_t cus = std::max(1, h->num_cus);
     const int64_t work = ((nq + 255) / 256) * ((nb + 255) / 256); // 256 x 256 tiles of the search
+    // (24 tiles per CU: 1 M rows x 512 queries 8.27 against 8.78 ms, 500 k x 1024 8.16 against 8.47, 400 k x 1024 7.11 against 7.3,
+    // 200 k x 2048 6.73 against 6.80 -- the bound was 32 until late in round 5.)
     // (from ONE wide query tile on: 10 M rows x 256 / 512 / 768 / 1024 / 1536 queries 38.1 / 79.1 / 117.6 / 152.4 / 234.4 ms against
     // 41.4 / 89.4 / 130.8 / 172.0 / 248.8 on the 128 x 128 tile, one box; until late in round 5 the bound was 2048)
-    return nq >= dev_knob("KNN355_BIG_MIN_NQ", 256) && work >= (int64_t)dev_knob("KNN355_BIG_MIN_TILES_PER_CU", 32) * cus;
+    return nq >= dev_knob("KNN355_BIG_MIN_NQ", 256) && work >= (int64_t)dev_knob("KNN355_BIG_MIN_TILES_PER_CU", 24) * cus;
 }
 
 static void make_plan(const knn_index_s *h, int64_t nb, int64_t nq, int k, bool seeded, ScanPlan &pl, bool allow_pairs = false, bool allow_big = true)
@@ -4471,14 +4473,25 @@ extern "C" int knn_merge_keys_dev(knn_handle h, const uint64_t *keys_dev, int32_
 // and k <= 1536.  Returns 1 when it ran (D_dev / I_dev hold all n x k results, the verification flag is still to be
 // read by the caller), 0 when the plain path should be used, < 0 on error.
 // will self_search_symmetric take this search?  (asked BEFORE the caller sets aside device memory for the whole n x k result)
+// The statistical sample of a symmetric self-search: every 64th row from 131 072 rows on (Pfam-sized k = 100 / 1000 340.0 / 356.8 ms
+// against 348.7 / 366.2 with every 32nd -- the sample pass is 6 % of that search --, 100 k rows 89.2 against 90.8, 60 k rows and
+// fewer: within 1 % either way; CATH-sized: 3.06 against 2.87 ms; until late in round 5 the step to 64 came at 2^20 rows).  ONE
+// function: the rank j and the sample it is taken from must belong together (a rank worked out for a sparser sample is too tight
+// a bound on a denser one: every verification fails and the plain path repeats the search).
+static int sym_stat_stride(int64_t n)
+{
+    int st = n >= (1 << 17) ? 64 : 32;
+#ifdef KNN355_DEV
+    if (getenv("KNN355_STAT_STRIDE")) st = atoi(getenv("KNN355_STAT_STRIDE"));
+#endif
+    return st;
+}
+
 static bool self_search_symmetric_eligible(const knn_index_s *h, int k, int *j_out = nullptr, int *qcap_out = nullptr)
 {
     const int64_t n = h->ntotal;
     if (n < dev_knob("KNN355_SYM_MIN_N", 3000) || k > KNN_REGISTER_SELECT_MAX_K || k >= n || (h->flags & (8 | 16 | 512 | 1024)) || h->force_qt || h->force_chunks || h->approx16) return false;
-    int st = n >= (1 << 20) ? 64 : 32;
-#ifdef KNN355_DEV
-    if (getenv("KNN355_STAT_STRIDE")) st = atoi(getenv("KNN355_STAT_STRIDE"));
-#endif
+    const int st = sym_stat_stride(n);
     const int64_t S = view_rows(n, st, 0);
     const int j = stat_seed_rank(S, n, k);
     if (j <= 0) return false;
@@ -4502,10 +4515,7 @@ static int self_search_symmetric(knn_index_s *h, int k, float *D_dev, int64_t *I
     const int64_t n = h->ntotal;
     int j = 0, qcap = 0;
     if (!self_search_symmetric_eligible(h, k, &j, &qcap)) return 0;
-    int st = n >= (1 << 20) ? 64 : 32;
-#ifdef KNN355_DEV
-    if (getenv("KNN355_STAT_STRIDE")) st = atoi(getenv("KNN355_STAT_STRIDE"));
-#endif
+    const int st = sym_stat_stride(n);
     const int64_t S = view_rows(n, st, 0);
     const double expect = 1.3 * (double)j * (double)n / (double)S + 1.25 * k;
     ScanPlan pl;

@@ -1211,3 +1211,23 @@ def test_results_that_are_kept_stop_taking_new_page_locked_blocks(gpu_faiss):
     gc.collect()
     D, I = idx.search(xq, 300)
     assert not D.flags.owndata and not I.flags.owndata
+
+
+@pytest.mark.parametrize("k", [20, 1000])
+def test_symmetric_self_search_beyond_131072_rows_keeps_its_estimate(gpu_faiss, oracle, k):
+    """From 131 072 rows on the symmetric self-search samples every 64th row (every 32nd below): the rank of its bound and the
+    sample it is read from belong together -- the search stays on the symmetric launch, no estimate fails (a mismatch would
+    still return the exact result, through the plain path's repeat, at three times the cost)."""
+    rng = np.random.default_rng(140 + k)
+    n, d = 140_000, 16
+    cent = rng.standard_normal((700, d), dtype=np.float32)
+    x = (cent[rng.integers(0, 700, n)] + 0.4 * rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
+    idx = gpu_faiss.IndexFlat(d, 0)
+    idx.add(x)
+    before = idx.last_seed()["stat_redo"]
+    D, I = idx.search_self(k)
+    assert idx.last_scan()["kernel"] == "flat_scan_q128_d128_sym" and idx.last_seed()["stride"] == 64, (idx.last_scan(), idx.last_seed())
+    assert idx.last_seed()["stat_redo"] == before
+    sample = rng.choice(n, 16, replace=False)
+    Do, Io = oracle.flat_search(x, x[sample], k, 0, l2_mode=1)
+    _assert_same(D[sample], I[sample], Do, Io)
